@@ -1,0 +1,266 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ from the REFERENCE itself.
+
+Runs only in the build container (needs /root/reference; never on the GPU box).  It imports
+/root/reference/Main_Final.py in-process (with empty `torchvision` stub modules, because that
+file imports torchvision at the top and torchvision is not installed), fills the reference
+modules with weights from the repo's portable generator, runs them on portable inputs and
+stores inputs-by-seed + outputs.  Nothing from the reference's source is copied: the
+fixtures are data (tensors, scalars, key lists).
+
+Usage:  cd /root/repo && python tests/golden/make_golden.py
+"""
+import importlib
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+for name in ("torchvision", "torchvision.transforms"):
+    sys.modules.setdefault(name, types.ModuleType(name))
+sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+import matplotlib  # noqa: E402
+
+matplotlib.use("Agg")
+sys.path.insert(0, "/root/reference")
+import Main_Final as ref  # noqa: E402
+
+oracle = importlib.import_module("oracle.robust_unet_ref")
+pkg_data = importlib.import_module("eusipco-2026-robust-unet_amd.data")
+prng = importlib.import_module("eusipco-2026-robust-unet_amd.portable_rng")
+
+torch.set_num_threads(8)
+torch.manual_seed(0)
+
+
+class InjectedDropout2d(torch.nn.Module):
+    """Stands in for the reference block's nn.Dropout2d so the Bernoulli draw is reproducible."""
+
+    def __init__(self, mask):
+        super().__init__()
+        self.mask = mask
+
+    def forward(self, x):
+        return x * self.mask[:, :, None, None] if self.training else x
+
+
+def summary(t, nsample=2048):
+    t = t.detach().double().reshape(-1)
+    stride = max(1, t.numel() // nsample)
+    return {"stat": np.array([t.mean().item(), t.std().item(), t.min().item(), t.max().item(),
+                              t.abs().sum().item()]),
+            "sample": t[::stride][:nsample].float().numpy(), "stride": stride, "numel": t.numel()}
+
+
+def put(out, key, t, full=False):
+    if full:
+        out[key] = t.detach().float().numpy()
+    else:
+        s = summary(t)
+        out[key + "/stat"] = s["stat"]
+        out[key + "/sample"] = s["sample"]
+        out[key + "/meta"] = np.array([s["stride"], s["numel"]], dtype=np.int64)
+
+
+def get_sub(model, dotted):
+    m = model
+    for part in dotted.split("."):
+        m = m[int(part)] if part.isdigit() else getattr(m, part)
+    return m
+
+
+def model_case(base, n, size, seed, tag):
+    """Full train step through the reference: fwd taps, loss, grads, BN buffers, one Adam step."""
+    out = {}
+    model = ref.RobustUNet(3, 1, base)
+    st = oracle.init_state(3, 1, base, seed=seed, perturb_bn=True)
+    missing = model.load_state_dict(st, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    masks = oracle.dropout_masks(n, base, seed=seed)
+    for pre, _ in oracle.DROPOUT_SITES:
+        get_sub(model, pre).dropout = InjectedDropout2d(masks[pre])
+    x, y = pkg_data.synthetic_batch(n, size, seed=seed)
+    model.train()
+    taps = {}
+    hooks = []
+    for name in ("inc", "down1", "down2", "down3", "bottleneck", "up4", "att4", "dec4", "up3", "att3", "dec3",
+                 "up2", "att2", "dec2", "up1", "att1", "dec1", "outc.0"):
+        hooks.append(get_sub(model, name).register_forward_hook(
+            lambda m, i, o, name=name: taps.__setitem__(name, o.detach().clone())))
+    hooks.append(get_sub(model, "bottleneck.1").register_forward_hook(
+        lambda m, i, o: taps.__setitem__("bottleneck.1", o.detach().clone())))
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-4)
+    opt.zero_grad()
+    prob = model(x)
+    loss = torch.nn.BCELoss()(prob, y)
+    loss.backward()
+    for h in hooks:
+        h.remove()
+    put(out, "prob", prob, full=True)
+    put(out, "logit", taps["outc.0"], full=True)
+    for k, v in taps.items():
+        if k != "outc.0":
+            put(out, "tap/" + k, v)
+    out["loss"] = np.array(loss.item(), dtype=np.float64)
+    names = [k for k, _ in model.named_parameters()]
+    out["grad_norm"] = np.array([p.grad.double().norm().item() for _, p in model.named_parameters()])
+    out["grad_abs_sum"] = np.array([p.grad.double().abs().sum().item() for _, p in model.named_parameters()])
+    for k, p in model.named_parameters():  # small grads in full, big ones sampled
+        put(out, "grad/" + k, p.grad, full=p.numel() <= 4096)
+    for k, b in model.named_buffers():
+        if not k.endswith("num_batches_tracked"):
+            put(out, "buf/" + k, b, full=b.numel() <= 4096)
+    out["num_batches_tracked"] = np.array([b.item() for k, b in model.named_buffers()
+                                           if k.endswith("num_batches_tracked")], dtype=np.int64)
+    opt.step()
+    out["param_after_step_sum"] = np.array([p.detach().double().sum().item() for p in model.parameters()])
+    out["param_delta_abs_sum"] = np.array([(p.detach().double() - st[k].double()).abs().sum().item()
+                                           for k, p in model.named_parameters()])
+    # eval-mode forward with the UPDATED weights and buffers + per-image metrics
+    model.eval()
+    with torch.no_grad():
+        pe = model(x)
+    put(out, "eval_prob", pe, full=True)
+    ev = ref.ModelEvaluator(torch.device("cpu"))
+    mets = [ev.calculate_metrics(pe[i, 0], y[i, 0]) for i in range(n)]
+    for key in ("accuracy", "iou", "precision", "recall", "f1_score"):
+        out["eval_metric/" + key] = np.array([m[key] for m in mets], dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, f"model_{tag}.npz"), **out)
+    with open(os.path.join(HERE, f"model_{tag}.json"), "w") as f:
+        json.dump({"base": base, "n": n, "size": size, "seed": seed, "param_names": names,
+                   "lr": 1e-4, "weight_decay": 1e-4}, f, indent=1)
+    print(tag, "loss", loss.item(), "iou", out["eval_metric/iou"])
+
+
+def state_dict_case():
+    model = ref.RobustUNet()
+    sd = model.state_dict()
+    desc = [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in sd.items()]
+    with open(os.path.join(HERE, "state_dict_keys_base64.json"), "w") as f:
+        json.dump({"n_params": sum(p.numel() for p in model.parameters()), "entries": desc,
+                   "param_order": [k for k, _ in model.named_parameters()]}, f)
+    # init statistics of the reference's own initialiser (distribution parity, not values)
+    stats = {k: [float(v.float().mean()), float(v.float().std()), float(v.float().min()), float(v.float().max())]
+             for k, v in sd.items() if v.dtype == torch.float32 and v.numel() > 1}
+    with open(os.path.join(HERE, "init_stats_base64.json"), "w") as f:
+        json.dump(stats, f)
+    print("state_dict entries", len(desc))
+
+
+def block_cases():
+    """Reference blocks in isolation, train mode, fwd + bwd; full small tensors."""
+    out = {}
+    n, c_in, c_out, hw = 2, 32, 48, 8
+    x = torch.from_numpy(prng.normal_f32((n, c_in, hw, hw), 11)).requires_grad_(True)
+    gy = torch.from_numpy(prng.normal_f32((n, c_out, hw, hw), 12))
+
+    def load(mod, seed):
+        sd = mod.state_dict()
+        for k in sd:
+            if sd[k].dtype == torch.float32 and not k.endswith(("running_mean", "running_var")):
+                scale = 0.3 if sd[k].dim() > 1 else 0.2
+                mean = 1.0 if (k.endswith("weight") and sd[k].dim() == 1) else 0.0
+                sd[k] = torch.from_numpy(prng.normal_f32(tuple(sd[k].shape), prng.name_seed(k, seed), scale, mean))
+        mod.load_state_dict(sd)
+        return {k: v.clone() for k, v in sd.items()}
+
+    def run(tag, mod, inputs, gout, seed):
+        sd0 = load(mod, seed)
+        mod.train()
+        y = mod(*inputs)
+        y.backward(gout)
+        for k, v in sd0.items():
+            out[f"{tag}/state/{k}"] = v.numpy()
+        out[f"{tag}/y"] = y.detach().numpy()
+        for i, t in enumerate(inputs):
+            out[f"{tag}/x{i}"] = t.detach().numpy()
+            out[f"{tag}/dx{i}"] = t.grad.numpy()
+            t.grad = None
+        out[f"{tag}/gy"] = gout.numpy()
+        for k, p in mod.named_parameters():
+            out[f"{tag}/grad/{k}"] = p.grad.numpy()
+        for k, b in mod.named_buffers():
+            out[f"{tag}/buf_after/{k}"] = b.numpy()
+
+    rb = ref.ResidualBlock(c_in, c_out, dropout_rate=0.2)
+    mask = torch.from_numpy(prng.bernoulli_keep((n, c_out), 13, 0.2) / np.float32(0.8))
+    rb.dropout = InjectedDropout2d(mask)
+    out["rb/mask"] = mask.numpy()
+    run("rb", rb, [x], gy, 21)
+
+    xi = torch.from_numpy(prng.normal_f32((n, c_out, hw, hw), 14)).requires_grad_(True)
+    rbi = ref.ResidualBlock(c_out, c_out, dropout_rate=0.3)
+    maski = torch.from_numpy(prng.bernoulli_keep((n, c_out), 15, 0.3) / np.float32(0.7))
+    rbi.dropout = InjectedDropout2d(maski)
+    out["rbi/mask"] = maski.numpy()
+    run("rbi", rbi, [xi], gy, 22)
+
+    xd = torch.from_numpy(prng.normal_f32((n, 32, hw, hw), 16)).requires_grad_(True)
+    gd = torch.from_numpy(prng.normal_f32((n, 64, hw, hw), 17))
+    run("dil", ref.DilatedBlock(32, 64), [xd], gd, 23)
+
+    g = torch.from_numpy(prng.normal_f32((n, 32, hw, hw), 18)).requires_grad_(True)
+    xs = torch.from_numpy(prng.normal_f32((n, 32, hw, hw), 19)).requires_grad_(True)
+    ga = torch.from_numpy(prng.normal_f32((n, 32, hw, hw), 20))
+    run("att", ref.AttentionGate(32, 32, 16), [g, xs], ga, 24)
+
+    xc = torch.from_numpy(prng.normal_f32((n, 32, hw, hw), 25)).requires_grad_(True)
+    gc = torch.from_numpy(prng.normal_f32((n, 32, hw, hw), 26))
+    run("ca", ref.ChannelAttention(32), [xc], gc, 27)
+    xsa = torch.from_numpy(prng.normal_f32((n, 32, hw, hw), 28)).requires_grad_(True)
+    run("sa", ref.SpatialAttention(), [xsa], gc, 29)
+    np.savez_compressed(os.path.join(HERE, "blocks.npz"), **out)
+    print("blocks:", len(out), "arrays")
+
+
+def labelme_cases():
+    """Synthetic Labelme JSON files (committed as data) -> masks from the reference rasteriser."""
+    d = os.path.join(HERE, "labelme")
+    os.makedirs(d, exist_ok=True)
+    cases = {
+        "float_coords": {"shapes": [{"label": "Water", "points": [[3.7, 2.2], [40.9, 5.5], [35.1, 44.8], [6.2, 30.0]]}]},
+        "two_labels": {"shapes": [{"label": "sea", "points": [[0, 0], [20, 0], [20, 20], [0, 20]]},
+                                  {"label": "land", "points": [[30, 30], [60, 30], [60, 60], [30, 60]]},
+                                  {"label": "海水", "points": [[40, 5], [63, 5], [50, 28]]}]},
+        "too_few_points": {"shapes": [{"label": "water", "points": [[1, 1], [30, 30]]},
+                                      {"label": "水体", "points": [[10, 50], [50, 50], [30, 20.9]]}]},
+        "no_shapes": {"version": "5.0"},
+        "out_of_bounds": {"shapes": [{"label": "WATER", "points": [[-10, -10], [80, 10], [70, 90], [-5, 40]]}]},
+    }
+    out = {}
+    ds = ref.CoastalDataset([], [])
+    for name, body in cases.items():
+        p = os.path.join(d, name + ".json")
+        with open(p, "w", encoding="utf-8") as f:
+            json.dump(body, f, ensure_ascii=False)
+        out[name] = ds.create_mask_from_labelme(p, (64, 48))
+    with open(os.path.join(d, "bad_json.json"), "w") as f:
+        f.write("{ this is not json")
+    out["bad_json"] = ds.create_mask_from_labelme(os.path.join(d, "bad_json.json"), (64, 48))
+    out["missing_file"] = ds.create_mask_from_labelme(os.path.join(d, "does_not_exist.json"), (64, 48))
+    np.savez_compressed(os.path.join(HERE, "labelme_masks.npz"), **out)
+    # metrics edge cases through the reference's calculate_metrics
+    ev = ref.ModelEvaluator(torch.device("cpu"))
+    pr = torch.from_numpy(prng.uniform_f32((6, 32, 32), 41))
+    tg = (torch.from_numpy(prng.uniform_f32((6, 32, 32), 42)) > 0.5).float()
+    pr[4].zero_(); tg[4].zero_()          # empty union
+    pr[5].fill_(0.5); tg[5].fill_(1.0)    # strict '>' threshold: 0.5 is NOT positive
+    mets = [ev.calculate_metrics(pr[i], tg[i]) for i in range(6)]
+    np.savez_compressed(os.path.join(HERE, "metrics.npz"), pred=pr.numpy(), target=tg.numpy(),
+                        **{k: np.array([m[k] for m in mets], dtype=np.float64) for k in mets[0]})
+    print("labelme + metrics done")
+
+
+if __name__ == "__main__":
+    state_dict_case()
+    labelme_cases()
+    block_cases()
+    model_case(base=16, n=2, size=64, seed=3, tag="b16_n2_s64")
+    model_case(base=64, n=2, size=64, seed=5, tag="b64_n2_s64")
