@@ -1,0 +1,540 @@
+// Implicit-GEMM convolutions on the fp32 matrix cores of gfx950 (v_mfma_f32_32x32x2_f32).
+//
+// Replaces the ATen/oneDNN kernels behind every nn.Conv2d / nn.ConvTranspose2d of the reference's
+// RobustUNet (/root/reference/Main_Final.py:157,159,172,126,131,205-208,261-270) for forward, data
+// gradient and weight gradient.  One kernel template serves 1x1 / 3x3 (dilation 1,2,4) convolutions
+// and the k2-s2 transposed convolution; the geometry struct says how a GEMM row (a pixel of the
+// iteration space) maps to source and destination pixels.
+//
+// Data layout in HBM: activations NHWC fp32 (pixel stride `ld` floats, so a tensor may be a channel
+// slice of a wider concat buffer); weights "HWIO": w[tap][cin][cout], cout contiguous.
+//
+// fwd/dgrad kernel:  out[p][n] = sum_tap sum_k  src[pix(p,tap)][k] * B_tap[k][n]
+//   GEMM M = pixels (tile BM), N = output channels (tile BN), K = taps x channels (step 16 channels).
+//   A tile (BM x 16) and B tile (16 x BN) are register-staged into double-buffered LDS
+//   (global_load_dwordx4 issued one k-step ahead, ds_write after the MFMAs of the current step),
+//   one barrier per k-step.  A rows are padded to 20 floats so the ds_read_b128 fragment reads are
+//   bank-conflict free; lane (i, h) of a wave reads 4 consecutive k for row i and feeds them to 4
+//   MFMAs (the k order inside a group of 8 is permuted identically for A and B).
+// wgrad kernel:      dW[tap][ci][co] = sum_p  x[pix(p,tap)][ci] * dy[p][co]
+//   GEMM M = cin, N = cout, K = pixels (step 16 pixels); split over pixel ranges (grid.z) into
+//   partial slabs that a second kernel sums in a fixed order (bitwise reproducible, no atomics).
+#include "runet_common.h"
+#include "../../include/runet_hip.h"
+
+namespace {
+
+struct IGemmArgs {
+    const float* x; int ldx;      // A source, [Nimg, Hin, Win, ldx]
+    const float* w; long w_tap_stride; int w_sk, w_sn;   // B(tap,k,n) = w[tap*w_tap_stride + k*w_sk + n*w_sn]
+    const float* bias;            // [Ncols] or nullptr
+    float* y; int ldy;            // destination [Nimg, Hout, Wout, ldy]
+    int K, Kx, Kvalid, Ncols;     // K: k-loop extent (multiple of 16); x holds Kx channels; rows >= Kvalid of B are zero
+    int Nimg, H, W;               // iteration space
+    int Hin, Win, a_scale;        // source pixel = (h*a_scale + bh + r*tdh, w*a_scale + bw + s*tdw)
+    int KH, KW, tdh, tdw, bh, bw;
+    int Hout, Wout, o_scale, o_dh, o_dw;   // destination pixel = (h*o_scale + o_dh, w*o_scale + o_dw)
+    int z_taps;                   // >0: blockIdx.z selects one weight tap AND the destination offset (convT fwd)
+    int accumulate;               // y += result
+};
+
+template <int BM, int BN, int WM, int WN, bool KCONTIG>
+__global__ __launch_bounds__(256, 2) void igemm_kernel(IGemmArgs g) {
+    constexpr int LDA = 20;
+    constexpr int LDB = BN + 4;
+    constexpr int A_ELEMS = BM * LDA;
+    constexpr int B_ELEMS = 16 * LDB;
+    constexpr int STAGE = A_ELEMS + B_ELEMS;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int WAVES_N = BN / WN;
+    static_assert((BM / WM) * WAVES_N == 4, "4 waves per block");
+    constexpr int AROWS = BM / 64;
+    constexpr int BREGS = (BN >= 64) ? BN / 64 : 1;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm0 = (wid / WAVES_N) * WM, wn0 = (wid % WAVES_N) * WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const long P = (long)g.Nimg * g.H * g.W;
+    const long m0 = (long)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const int HW = g.H * g.W;
+
+    const float* wbase = g.w;
+    int o_dh = g.o_dh, o_dw = g.o_dw;
+    if (g.z_taps > 0) {
+        wbase += (long)blockIdx.z * g.w_tap_stride;
+        o_dh = blockIdx.z / g.z_taps;   // z_taps = taps per row (2 for the 2x2 transposed conv)
+        o_dw = blockIdx.z % g.z_taps;
+    }
+
+    // ---- per-thread A staging rows ----
+    const int akq = tid & 3;
+    long a_img[AROWS];
+    int a_h[AROWS], a_w[AROWS];
+    bool a_ok[AROWS];
+#pragma unroll
+    for (int i = 0; i < AROWS; ++i) {
+        const long p = m0 + (tid >> 2) + 64 * i;
+        a_ok[i] = p < P;
+        const long pp = a_ok[i] ? p : 0;
+        const int n = (int)(pp / HW);
+        const int rem = (int)(pp - (long)n * HW);
+        const int h = rem / g.W;
+        a_img[i] = (long)n * g.Hin * g.Win;
+        a_h[i] = h * g.a_scale + g.bh;
+        a_w[i] = (rem - h * g.W) * g.a_scale + g.bw;
+    }
+
+    const int KC = g.K >> 4;
+    const int ntaps = (g.z_taps > 0) ? 1 : g.KH * g.KW;
+    const int nks = ntaps * KC;
+
+    f32x4 ra[AROWS];
+    f32x4 rb[BREGS];
+    int ld_tr = 0, ld_ts = 0, ld_kc = 0, ld_tap = 0;   // counters of the NEXT tile to load
+
+    auto load_tile = [&]() {
+        const int dh = ld_tr * g.tdh, dw = ld_ts * g.tdw;
+        const int kofs = ld_kc * 16;
+#pragma unroll
+        for (int i = 0; i < AROWS; ++i) {
+            const int ih = a_h[i] + dh, iw = a_w[i] + dw;
+            const bool ok = a_ok[i] && (unsigned)ih < (unsigned)g.Hin && (unsigned)iw < (unsigned)g.Win && kofs + akq * 4 < g.Kx;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ok) v = *reinterpret_cast<const f32x4*>(g.x + ((a_img[i] + (long)ih * g.Win + iw) * g.ldx + kofs + akq * 4));
+            ra[i] = v;
+        }
+        const float* wt = wbase + (long)ld_tap * g.w_tap_stride;
+        if constexpr (!KCONTIG) {   // n contiguous: 16 k-rows x BN/4 float4
+            constexpr int NQ = BN / 4;
+            constexpr int KSTEP = 256 / NQ;
+#pragma unroll
+            for (int i = 0; i < BREGS; ++i) {
+                const int nq = tid % NQ, kr = tid / NQ + KSTEP * i;
+                const int k = kofs + kr, n = n0 + nq * 4;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (kr < 16 && k < g.Kvalid && n < g.Ncols) v = *reinterpret_cast<const f32x4*>(wt + (long)k * g.w_sk + n);
+                rb[i] = v;
+            }
+        } else {   // k contiguous: BN n-rows x 4 float4
+#pragma unroll
+            for (int i = 0; i < BREGS; ++i) {
+                const int nr = (tid >> 2) + 64 * i;
+                const int n = n0 + nr, k = kofs + akq * 4;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (nr < BN && n < g.Ncols && k < g.Kvalid) v = *reinterpret_cast<const f32x4*>(wt + (long)n * g.w_sn + k);
+                rb[i] = v;
+            }
+        }
+        // advance counters: kc fastest, then tap column, then tap row
+        if (++ld_kc == KC) {
+            ld_kc = 0;
+            ++ld_tap;
+            if (++ld_ts == g.KW) { ld_ts = 0; ++ld_tr; }
+        }
+    };
+
+    auto store_tile = [&](int buf) {
+        float* As = smem + buf * STAGE;
+        float* Bs = As + A_ELEMS;
+#pragma unroll
+        for (int i = 0; i < AROWS; ++i)
+            *reinterpret_cast<f32x4*>(As + ((tid >> 2) + 64 * i) * LDA + akq * 4) = ra[i];
+        if constexpr (!KCONTIG) {
+            constexpr int NQ = BN / 4;
+            constexpr int KSTEP = 256 / NQ;
+#pragma unroll
+            for (int i = 0; i < BREGS; ++i) {
+                const int nq = tid % NQ, kr = tid / NQ + KSTEP * i;
+                if (kr < 16) *reinterpret_cast<f32x4*>(Bs + kr * LDB + nq * 4) = rb[i];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < BREGS; ++i) {
+                const int nr = (tid >> 2) + 64 * i;
+                if (nr < BN) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) Bs[(akq * 4 + e) * LDB + nr] = rb[i][e];
+                }
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    load_tile();
+    store_tile(0);
+    __syncthreads();
+
+    int cur = 0;
+    for (int ks = 0; ks < nks; ++ks) {
+        const bool more = ks + 1 < nks;
+        if (more) load_tile();
+        const float* As = smem + cur * STAGE;
+        const float* Bs = As + A_ELEMS;
+#pragma unroll
+        for (int kb = 0; kb < 16; kb += 8) {
+            f32x4 af[TM];
+            float bf[TN][4];
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+                af[a] = *reinterpret_cast<const f32x4*>(As + (wm0 + a * 32 + li) * LDA + kb + 4 * lh);
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bf[b][q] = Bs[(kb + 4 * lh + q) * LDB + wn0 + b * 32 + li];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][q], bf[b][q], acc[a][b], 0, 0, 0);
+        }
+        if (more) store_tile(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue: D[row = pixel][col = n]; lane holds col (lane&31), rows (r&3)+8*(r>>2)+4*(lane>>5) ----
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+        const int n = n0 + wn0 + b * 32 + li;
+        const bool n_ok = n < g.Ncols;
+        const float bv = (g.bias != nullptr && n_ok) ? g.bias[n] : 0.f;
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const long p = m0 + wm0 + a * 32 + row;
+                if (n_ok && p < P) {
+                    const int nimg = (int)(p / HW);
+                    const int rem = (int)(p - (long)nimg * HW);
+                    const int h = rem / g.W, w = rem - h * g.W;
+                    const long op = ((long)nimg * g.Hout + (h * g.o_scale + o_dh)) * g.Wout + (w * g.o_scale + o_dw);
+                    float* dst = g.y + op * g.ldy + n;
+                    float v = acc[a][b][r] + bv;
+                    if (g.accumulate) v += *dst;
+                    *dst = v;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ wgrad
+struct WGradArgs {
+    const float* x; int ldx;     // [Nimg, Hin, Win, ldx], channels [0, Kci)
+    const float* dy; int ldy;    // [Nimg, Hout, Wout, ldy], channels [0, Nco)
+    float* out;                  // slabs: [split][ntaps][Kvalid][Nco]
+    int Kci, Kvalid, Nco;        // Kci multiple of 16 (padded read width of x); only ci < Kvalid are written
+    int Nimg, H, W;              // iteration space (pixels summed over)
+    int Hin, Win, a_scale, KH, KW, tdh, tdw, bh, bw;   // x pixel = (h*a_scale + bh + r*tdh, ...)
+    int Hout, Wout, o_scale;     // dy pixel = (h*o_scale + o_dh, w*o_scale + o_dw)
+    int tap_on_output;           // 1: tap (r,s) offsets the dy pixel (transposed conv), x pixel unshifted
+    long pix_per_split;          // multiple of 16
+};
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(WGradArgs g) {
+    constexpr int LDA = BM + 4, LDB = BN + 4;
+    constexpr int A_ELEMS = 16 * LDA, B_ELEMS = 16 * LDB, STAGE = A_ELEMS + B_ELEMS;
+    constexpr int TM = WM / 32, TN = WN / 32, WAVES_N = BN / WN;
+    static_assert((BM / WM) * WAVES_N == 4, "4 waves per block");
+    constexpr int AQ = BM / 4, BQ = BN / 4;              // float4 per pixel row
+    constexpr int AREGS = (16 * AQ + 255) / 256, BREGS = (16 * BQ + 255) / 256;
+    constexpr int APSTEP = 256 / AQ, BPSTEP = 256 / BQ;  // pixel rows covered per pass (AQ,BQ <= 64... see launch)
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm0 = (wid / WAVES_N) * WM, wn0 = (wid % WAVES_N) * WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int n_tiles = (g.Nco + BN - 1) / BN;
+    const int ci0 = (blockIdx.x / n_tiles) * BM, co0 = (blockIdx.x % n_tiles) * BN;
+    const int tap = blockIdx.y, tr = tap / g.KW, ts = tap % g.KW;
+    const long P = (long)g.Nimg * g.H * g.W;
+    const long p_begin = (long)blockIdx.z * g.pix_per_split;
+    long p_end = p_begin + g.pix_per_split;
+    if (p_end > P) p_end = P;
+    const int HW = g.H * g.W;
+
+    int xdh = g.bh, xdw = g.bw, ydh = 0, ydw = 0;
+    if (g.tap_on_output) { ydh = tr; ydw = ts; } else { xdh += tr * g.tdh; xdw += ts * g.tdw; }
+
+    f32x4 ra[AREGS], rb[BREGS];
+    auto load_tile = [&](long pk) {   // pk: first pixel of the 16-pixel k-step
+#pragma unroll
+        for (int i = 0; i < AREGS; ++i) {
+            const int cq = tid % AQ, pr = tid / AQ + APSTEP * i;
+            const long p = pk + pr;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (pr < 16 && p < p_end && ci0 + cq * 4 < g.Kci) {
+                const int n = (int)(p / HW);
+                const int rem = (int)(p - (long)n * HW);
+                const int h = rem / g.W, w = rem - h * g.W;
+                const int ih = h * g.a_scale + xdh, iw = w * g.a_scale + xdw;
+                if ((unsigned)ih < (unsigned)g.Hin && (unsigned)iw < (unsigned)g.Win)
+                    v = *reinterpret_cast<const f32x4*>(g.x + (((long)n * g.Hin + ih) * g.Win + iw) * g.ldx + ci0 + cq * 4);
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < BREGS; ++i) {
+            const int cq = tid % BQ, pr = tid / BQ + BPSTEP * i;
+            const long p = pk + pr;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (pr < 16 && p < p_end && co0 + cq * 4 < g.Nco) {
+                const int n = (int)(p / HW);
+                const int rem = (int)(p - (long)n * HW);
+                const int h = rem / g.W, w = rem - h * g.W;
+                const long op = ((long)n * g.Hout + (h * g.o_scale + ydh)) * g.Wout + (w * g.o_scale + ydw);
+                v = *reinterpret_cast<const f32x4*>(g.dy + op * g.ldy + co0 + cq * 4);
+            }
+            rb[i] = v;
+        }
+    };
+    auto store_tile = [&](int buf) {
+        float* As = smem + buf * STAGE;
+        float* Bs = As + A_ELEMS;
+#pragma unroll
+        for (int i = 0; i < AREGS; ++i) {
+            const int cq = tid % AQ, pr = tid / AQ + APSTEP * i;
+            if (pr < 16) *reinterpret_cast<f32x4*>(As + pr * LDA + cq * 4) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < BREGS; ++i) {
+            const int cq = tid % BQ, pr = tid / BQ + BPSTEP * i;
+            if (pr < 16) *reinterpret_cast<f32x4*>(Bs + pr * LDB + cq * 4) = rb[i];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int nks = (int)((p_end - p_begin + 15) / 16);
+    if (nks > 0) {
+        load_tile(p_begin);
+        store_tile(0);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int ks = 0; ks < nks; ++ks) {
+        const bool more = ks + 1 < nks;
+        if (more) load_tile(p_begin + (long)(ks + 1) * 16);
+        const float* As = smem + cur * STAGE;
+        const float* Bs = As + A_ELEMS;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            float af[TM], bf[TN];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) af[a] = As[(2 * s + lh) * LDA + wm0 + a * 32 + li];
+#pragma unroll
+            for (int b = 0; b < TN; ++b) bf[b] = Bs[(2 * s + lh) * LDB + wn0 + b * 32 + li];
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
+        }
+        if (more) store_tile(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    const int ntaps = g.KH * g.KW;
+    float* slab = g.out + ((long)blockIdx.z * ntaps + tap) * g.Kvalid * g.Nco;
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+        const int co = co0 + wn0 + b * 32 + li;
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = ci0 + wm0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (co < g.Nco && ci < g.Kvalid) slab[(long)ci * g.Nco + co] = acc[a][b][r];
+            }
+    }
+}
+
+__global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, long n, int nsplit) {
+    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    if (i + 4 <= n) {
+        f32x4 s = *reinterpret_cast<const f32x4*>(slabs + i);
+        for (int k = 1; k < nsplit; ++k) s += *reinterpret_cast<const f32x4*>(slabs + (long)k * n + i);
+        *reinterpret_cast<f32x4*>(out + i) = s;
+    } else {
+        for (long j = i; j < n; ++j) {
+            float s = slabs[j];
+            for (int k = 1; k < nsplit; ++k) s += slabs[(long)k * n + j];
+            out[j] = s;
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, bool KC>
+void launch_igemm(const IGemmArgs& a, int gz, hipStream_t st) {
+    const long P = (long)a.Nimg * a.H * a.W;
+    dim3 grid(cdiv(P, BM), cdiv(a.Ncols, BN), gz);
+    const size_t lds = 2 * (BM * 20 + 16 * (BN + 4)) * sizeof(float);
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, KC>), grid, dim3(256), lds, st, a);
+}
+
+template <bool KC>
+void dispatch_igemm(const IGemmArgs& a, int gz, hipStream_t st) {
+    const long P = (long)a.Nimg * a.H * a.W;
+    if (a.Ncols <= 32) {
+        launch_igemm<128, 32, 32, 32, KC>(a, gz, st);
+    } else if (a.Ncols <= 64) {
+        if (P >= 256L * 512) launch_igemm<256, 64, 64, 64, KC>(a, gz, st);
+        else launch_igemm<128, 64, 64, 32, KC>(a, gz, st);
+    } else {
+        const long blocks128 = (long)cdiv(P, 128) * cdiv(a.Ncols, 128);
+        if (blocks128 >= 512 || (a.Ncols % 128 == 0 && blocks128 >= 256)) launch_igemm<128, 128, 64, 64, KC>(a, gz, st);
+        else launch_igemm<128, 64, 64, 32, KC>(a, gz, st);
+    }
+}
+
+}  // namespace
+
+extern "C" int runet_conv_igemm(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy,
+                                 int n_img, int h, int w_, int cin, int cin_w, int cout, int kh, int kw, int dil,
+                                 int mode, int accumulate, void* stream) {
+    RUNET_REQUIRE(x && w && y, "null pointer");
+    RUNET_REQUIRE(cin > 0 && cin % 4 == 0, "cin (channels read from x) must be a positive multiple of 4");
+    RUNET_REQUIRE(cin_w > 0 && cin_w <= cin, "cin_w (rows present in the weight) must be in (0, cin]");
+    RUNET_REQUIRE(cout > 0 && cout % 4 == 0, "cout must be a positive multiple of 4");
+    RUNET_REQUIRE(ldx >= cin && ldx % 4 == 0 && ldy % 4 == 0, "pixel strides must be multiples of 4 floats and cover the channels");
+    RUNET_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0 && ((uintptr_t)y % 16) == 0, "pointers must be 16-byte aligned");
+    RUNET_REQUIRE(n_img > 0 && h > 0 && w_ > 0, "empty iteration space");
+    RUNET_REQUIRE((kh == 1 && kw == 1) || (kh == 3 && kw == 3) || (kh == 2 && kw == 2), "kernel must be 1x1, 3x3 or 2x2(transposed)");
+    hipStream_t st = (hipStream_t)stream;
+    IGemmArgs a{};
+    a.x = x; a.ldx = ldx; a.w = w; a.bias = bias; a.y = y; a.ldy = ldy;
+    a.Nimg = n_img; a.accumulate = accumulate; a.KH = kh; a.KW = kw;
+    int gz = 1;
+    switch (mode) {
+    case RUNET_CONV_FWD:      // y[N,h,w,cout] = conv(x[N,h,w,cin], w[kh,kw,cin_w,cout]), 'same' padding = dil*(k-1)/2
+        RUNET_REQUIRE(kh != 2, "2x2 kernels are transposed-conv only");
+        RUNET_REQUIRE(ldy >= cout, "ldy < cout");
+        a.K = (cin + 15) / 16 * 16; a.Kx = cin; a.Kvalid = cin_w; a.Ncols = cout;
+        a.w_tap_stride = (long)cin_w * cout; a.w_sk = cout; a.w_sn = 1;
+        a.H = h; a.W = w_; a.Hin = h; a.Win = w_; a.a_scale = 1;
+        a.tdh = dil; a.tdw = dil; a.bh = -dil * (kh / 2); a.bw = -dil * (kw / 2);
+        a.Hout = h; a.Wout = w_; a.o_scale = 1;
+        dispatch_igemm<false>(a, gz, st);
+        break;
+    case RUNET_CONV_DGRAD:    // dx[N,h,w,cout_w... ] : here `cin` = channels of dy (=conv Cout), `cout` = conv Cin
+        // x := dy [N,h,w,cin], y := dx [N,h,w,cout];  w is the forward weight [kh,kw,cout(conv Cin),cin(conv Cout)]
+        RUNET_REQUIRE(kh != 2, "use RUNET_CONVT_DGRAD for 2x2");
+        RUNET_REQUIRE(cin_w == cin, "dgrad reads every output channel");
+        a.K = (cin + 15) / 16 * 16; a.Kx = cin; a.Kvalid = cin; a.Ncols = cout;
+        a.w_tap_stride = (long)cout * cin; a.w_sk = 1; a.w_sn = cin;
+        a.H = h; a.W = w_; a.Hin = h; a.Win = w_; a.a_scale = 1;
+        a.tdh = -dil; a.tdw = -dil; a.bh = dil * (kh / 2); a.bw = dil * (kw / 2);
+        a.Hout = h; a.Wout = w_; a.o_scale = 1;
+        dispatch_igemm<true>(a, gz, st);
+        break;
+    case RUNET_CONVT_FWD:     // y[N,2h,2w,cout] = convT_k2s2(x[N,h,w,cin]); w [2,2,cin,cout]
+        RUNET_REQUIRE(kh == 2 && kw == 2 && cin_w == cin, "transposed conv is 2x2 stride 2");
+        a.K = (cin + 15) / 16 * 16; a.Kx = cin; a.Kvalid = cin; a.Ncols = cout;
+        a.w_tap_stride = (long)cin * cout; a.w_sk = cout; a.w_sn = 1;
+        a.H = h; a.W = w_; a.Hin = h; a.Win = w_; a.a_scale = 1; a.KH = 1; a.KW = 1;
+        a.Hout = 2 * h; a.Wout = 2 * w_; a.o_scale = 2; a.z_taps = 2; gz = 4;
+        dispatch_igemm<false>(a, gz, st);
+        break;
+    case RUNET_CONVT_DGRAD:   // dx[N,h,w,cout(=convT Cin)] from dy[N,2h,2w,cin(=convT Cout)]; w [2,2,cout,cin]
+        RUNET_REQUIRE(kh == 2 && kw == 2 && cin_w == cin, "transposed conv is 2x2 stride 2");
+        a.K = (cin + 15) / 16 * 16; a.Kx = cin; a.Kvalid = cin; a.Ncols = cout;
+        a.w_tap_stride = (long)cout * cin; a.w_sk = 1; a.w_sn = cin;
+        a.H = h; a.W = w_; a.Hin = 2 * h; a.Win = 2 * w_; a.a_scale = 2; a.tdh = 1; a.tdw = 1;
+        a.Hout = h; a.Wout = w_; a.o_scale = 1;
+        dispatch_igemm<true>(a, gz, st);
+        break;
+    default:
+        RUNET_REQUIRE(false, "unknown mode");
+    }
+    RUNET_CHECK_LAUNCH();
+}
+
+extern "C" long runet_conv_wgrad_workspace_floats(int n_img, int h, int w_, int cin_w, int cout, int kh, int kw) {
+    // upper bound used by the host to size the slab workspace: at most 64 splits
+    return 64L * kh * kw * cin_w * cout;
+}
+
+static int pick_splits(long P, int tiles, int ntaps) {
+    const long base = (long)tiles * ntaps;
+    long want = (768 + base - 1) / base;            // aim for >= 3 blocks per CU
+    long maxs = (P + 255) / 256;                     // at least 256 pixels per split
+    if (want > maxs) want = maxs;
+    if (want > 64) want = 64;
+    if (want < 1) want = 1;
+    return (int)want;
+}
+
+extern "C" int runet_conv_wgrad(const float* x, int ldx, const float* dy, int ldy, float* dw, float* workspace,
+                                 long workspace_floats, int n_img, int h, int w_, int cin, int cin_w, int cout,
+                                 int kh, int kw, int dil, int transposed, void* stream) {
+    RUNET_REQUIRE(x && dy && dw, "null pointer");
+    RUNET_REQUIRE(cin > 0 && cin % 4 == 0 && cin_w > 0 && cin_w <= cin, "cin must be a multiple of 4, cin_w in (0, cin]");
+    RUNET_REQUIRE(cout > 0 && cout % 4 == 0, "cout must be a positive multiple of 4");
+    RUNET_REQUIRE(ldx >= cin && ldx % 4 == 0 && ldy >= cout && ldy % 4 == 0, "bad pixel strides");
+    RUNET_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0 && ((uintptr_t)dw % 16) == 0, "pointers must be 16-byte aligned");
+    RUNET_REQUIRE((kh == 1 && kw == 1) || (kh == 3 && kw == 3) || (kh == 2 && kw == 2 && transposed), "unsupported kernel size");
+    hipStream_t st = (hipStream_t)stream;
+    WGradArgs a{};
+    a.x = x; a.ldx = ldx; a.dy = dy; a.ldy = ldy;
+    a.Kci = cin; a.Kvalid = cin_w; a.Nco = cout;
+    a.Nimg = n_img; a.H = h; a.W = w_; a.Hin = h; a.Win = w_; a.a_scale = 1; a.KH = kh; a.KW = kw;
+    if (transposed) {
+        a.tap_on_output = 1; a.Hout = 2 * h; a.Wout = 2 * w_; a.o_scale = 2;
+    } else {
+        a.tdh = dil; a.tdw = dil; a.bh = -dil * (kh / 2); a.bw = -dil * (kw / 2);
+        a.Hout = h; a.Wout = w_; a.o_scale = 1;
+    }
+    const long P = (long)n_img * h * w_;
+    const int ntaps = kh * kw;
+    const bool big = (cin_w > 64 && cout > 64);
+    const int BMt = big ? 128 : 64, BNt = big ? 128 : 64;
+    const int tiles = cdiv(cin_w, BMt) * cdiv(cout, BNt);
+    int splits = pick_splits(P, tiles, ntaps);
+    const long wsize = (long)ntaps * cin_w * cout;
+    if (splits > 1 && (workspace == nullptr || workspace_floats < splits * wsize)) {
+        splits = workspace ? (int)(workspace_floats / wsize) : 1;
+        if (splits < 1) splits = 1;
+    }
+    long pps = (P + splits - 1) / splits;
+    pps = (pps + 15) / 16 * 16;
+    splits = cdiv(P, pps);
+    a.pix_per_split = pps;
+    a.out = (splits > 1) ? workspace : dw;
+    dim3 grid(tiles, ntaps, splits);
+    if (big) {
+        const size_t lds = 2 * (16 * (128 + 4) * 2) * sizeof(float);
+        hipLaunchKernelGGL((wgrad_kernel<128, 128, 64, 64>), grid, dim3(256), lds, st, a);
+    } else {
+        const size_t lds = 2 * (16 * (64 + 4) * 2) * sizeof(float);
+        hipLaunchKernelGGL((wgrad_kernel<64, 64, 32, 32>), grid, dim3(256), lds, st, a);
+    }
+    if (splits > 1) {
+        const int thr = 256;
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(wsize, thr * 4)), dim3(thr), 0, st, workspace, dw, wsize, splits);
+    }
+    RUNET_CHECK_LAUNCH();
+}

@@ -1,0 +1,467 @@
+// BatchNorm2d (train/eval), ReLU and Dropout2d as HBM-bound streaming kernels over NHWC fp32.
+//
+// Stands in for nn.BatchNorm2d / nn.ReLU / nn.Dropout2d at /root/reference/Main_Final.py:158,160,162,163,
+// 173,127,132,137,210,211 and for their autograd.  All kernels read/write 16 B per lane (float4 over the
+// channel axis, which is contiguous in NHWC), one pass per tensor; the channel-wise reductions keep a
+// shifted (sum, sum-of-squares) pair per thread, combine with Chan's parallel formula in LDS and in a
+// tiny second kernel in double precision, so the variance does not suffer from E[x^2]-E[x]^2 cancellation.
+//
+// Algorithmic HBM bytes per element: chan_stats 4 (read), bn_apply 8 (read+write), bn_bwd_reduce 8-12,
+// bn_bwd_apply 12-16.
+#include "runet_common.h"
+#include "../../include/runet_hip.h"
+#include <float.h>
+
+namespace {
+
+constexpr int TPB = 256;
+
+struct Welf { float n, mean, m2; };
+
+__device__ __forceinline__ void chan_combine(double& n, double& mean, double& m2, double nb, double mb, double m2b) {
+    if (nb == 0.0) return;
+    const double nt = n + nb;
+    const double d = mb - mean;
+    mean += d * (nb / nt);
+    m2 += m2b + d * d * (n * nb / nt);
+    n = nt;
+}
+
+// grid (chunks, N); thread owns VEC consecutive channels and every `rows`-th pixel of its chunk.
+template <int VEC, bool MINMAX>
+__global__ __launch_bounds__(TPB) void chan_stats_partial(const float* __restrict__ x, int ld, int HW, int C,
+                                                          int pix_per_chunk, float* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int cvec = C / VEC;
+    const int rows = TPB / cvec;
+    const int tid = threadIdx.x;
+    const int col = tid % cvec, row = tid / cvec;
+    const int n = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
+    const int p0 = chunk * pix_per_chunk;
+    const int p1 = min(HW, p0 + pix_per_chunk);
+    const bool active = row < rows;
+
+    float K[VEC], s1[VEC], s2[VEC], mx[VEC], mn[VEC];
+    int imx[VEC], imn[VEC];
+    int cnt = 0;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) { K[v] = 0.f; s1[v] = 0.f; s2[v] = 0.f; mx[v] = -FLT_MAX; mn[v] = FLT_MAX; imx[v] = 0; imn[v] = 0; }
+    if (active) {
+        const float* base = x + ((long)n * HW) * ld + col * VEC;
+        for (int p = p0 + row; p < p1; p += rows) {
+            float v[VEC];
+            if constexpr (VEC == 4) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(base + (long)p * ld);
+                v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+            } else {
+                v[0] = base[(long)p * ld];
+            }
+            if (cnt == 0) {
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) K[q] = v[q];
+            }
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) {
+                const float d = v[q] - K[q];
+                s1[q] += d;
+                s2[q] += d * d;
+                if constexpr (MINMAX) {
+                    if (v[q] > mx[q]) { mx[q] = v[q]; imx[q] = p; }
+                    if (v[q] < mn[q]) { mn[q] = v[q]; imn[q] = p; }
+                }
+            }
+            ++cnt;
+        }
+    }
+    // per-thread (n, mean, M2) -> LDS [row][C][3] (+ minmax [row][C][4])
+    float* w3 = sm;
+    float* wm = sm + rows * C * 3;
+    if (active) {
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+            const int c = col * VEC + q;
+            const float fn = (float)cnt;
+            const float mean = cnt ? K[q] + s1[q] / fn : 0.f;
+            const float m2 = cnt ? fmaxf(s2[q] - s1[q] * s1[q] / fn, 0.f) : 0.f;
+            float* d = w3 + (row * C + c) * 3;
+            d[0] = fn; d[1] = mean; d[2] = m2;
+            if constexpr (MINMAX) {
+                float* e = wm + (row * C + c) * 4;
+                e[0] = mx[q]; e[1] = mn[q]; e[2] = __int_as_float(imx[q]); e[3] = __int_as_float(imn[q]);
+            }
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += TPB) {
+        double n_ = 0, mean = 0, m2 = 0;
+        float bmx = -FLT_MAX, bmn = FLT_MAX;
+        int bimx = 0, bimn = 0;
+        for (int r = 0; r < rows; ++r) {
+            const float* d = w3 + (r * C + c) * 3;
+            chan_combine(n_, mean, m2, d[0], d[1], d[2]);
+            if constexpr (MINMAX) {
+                const float* e = wm + (r * C + c) * 4;
+                if (d[0] > 0.f) {
+                    const int i1 = __float_as_int(e[2]), i2 = __float_as_int(e[3]);
+                    if (e[0] > bmx || (e[0] == bmx && i1 < bimx)) { bmx = e[0]; bimx = i1; }
+                    if (e[1] < bmn || (e[1] == bmn && i2 < bimn)) { bmn = e[1]; bimn = i2; }
+                }
+            }
+        }
+        float* o = part + (((long)n * nchunks + chunk) * C + c) * (MINMAX ? 7 : 3);
+        o[0] = (float)n_; o[1] = (float)mean; o[2] = (float)m2;
+        if constexpr (MINMAX) { o[3] = bmx; o[4] = bmn; o[5] = __int_as_float(bimx); o[6] = __int_as_float(bimn); }
+    }
+}
+
+// one thread per (n, c): combine the chunks of image n
+template <bool MINMAX>
+__global__ void chan_stats_combine(const float* __restrict__ part, int N, int C, int nchunks, float* __restrict__ mean_nc,
+                                   float* __restrict__ m2_nc, float* __restrict__ max_nc, float* __restrict__ min_nc,
+                                   int* __restrict__ imax_nc, int* __restrict__ imin_nc) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * C) return;
+    const int n = i / C, c = i - n * C;
+    constexpr int S = MINMAX ? 7 : 3;
+    double n_ = 0, mean = 0, m2 = 0;
+    float bmx = -FLT_MAX, bmn = FLT_MAX;
+    int bimx = 0, bimn = 0;
+    for (int k = 0; k < nchunks; ++k) {
+        const float* o = part + (((long)n * nchunks + k) * C + c) * S;
+        chan_combine(n_, mean, m2, o[0], o[1], o[2]);
+        if constexpr (MINMAX) {
+            if (o[0] > 0.f) {   // chunks are in pixel order: strict comparisons keep the first occurrence
+                if (o[3] > bmx) { bmx = o[3]; bimx = __float_as_int(o[5]); }
+                if (o[4] < bmn) { bmn = o[4]; bimn = __float_as_int(o[6]); }
+            }
+        }
+    }
+    mean_nc[i] = (float)mean;
+    m2_nc[i] = (float)m2;
+    if constexpr (MINMAX) { max_nc[i] = bmx; min_nc[i] = bmn; imax_nc[i] = bimx; imin_nc[i] = bimn; }
+}
+
+__global__ void bn_finalize_kernel(const float* __restrict__ mean_nc, const float* __restrict__ m2_nc, int N, int C, long HW,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, float* run_mean,
+                                   float* run_var, long long* nbt, float momentum, float eps, int training,
+                                   float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ save_mean,
+                                   float* __restrict__ save_invstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && training && nbt) *nbt += 1;
+    if (c >= C) return;
+    double mean, var;
+    if (training) {
+        double n_ = 0, m = 0, m2 = 0;
+        for (int n = 0; n < N; ++n) chan_combine(n_, m, m2, (double)HW, mean_nc[n * C + c], m2_nc[n * C + c]);
+        mean = m;
+        var = m2 / n_;
+        if (run_mean) {
+            run_mean[c] = (float)((1.0 - momentum) * run_mean[c] + momentum * mean);
+            run_var[c] = (float)((1.0 - momentum) * run_var[c] + momentum * (m2 / (n_ - 1.0)));
+        }
+    } else {
+        mean = run_mean[c];
+        var = run_var[c];
+    }
+    const double invstd = 1.0 / sqrt(var + (double)eps);
+    const double g = gamma ? gamma[c] : 1.0, b = beta ? beta[c] : 0.0;
+    scale[c] = (float)(g * invstd);
+    shift[c] = (float)(b - mean * g * invstd);
+    if (save_mean) { save_mean[c] = (float)mean; save_invstd[c] = (float)invstd; }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(TPB) void bn_apply_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy,
+                                                       long P, int HW, int C, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, const float* __restrict__ mask, int relu) {
+    const int cvec = C / VEC;
+    const long total = P * cvec;
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
+        const long p = i / cvec;
+        const int c = (int)(i - p * cvec) * VEC;
+        float v[VEC];
+        if constexpr (VEC == 4) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(x + p * ldx + c);
+            v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+        } else v[0] = x[p * ldx + c];
+        const int n = (int)(p / HW);
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+            float r = v[q] * scale[c + q] + shift[c + q];
+            if (relu) r = fmaxf(r, 0.f);
+            if (mask) r *= mask[(long)n * C + c + q];
+            v[q] = r;
+        }
+        if constexpr (VEC == 4) {
+            f32x4 t = {v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(y + p * ldy + c) = t;
+        } else y[p * ldy + c] = v[0];
+    }
+}
+
+// partial sums of g and g*xhat per channel; g = dy [* mask[n,c] * (act > 0)]
+template <int VEC>
+__global__ __launch_bounds__(TPB) void bn_bwd_reduce_partial(const float* __restrict__ dy, int lddy, const float* __restrict__ x,
+                                                             int ldx, const float* __restrict__ act, int ldact, int HW, int C,
+                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                             const float* __restrict__ mask, int pix_per_chunk,
+                                                             float* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int cvec = C / VEC, rows = TPB / cvec, tid = threadIdx.x;
+    const int col = tid % cvec, row = tid / cvec;
+    const int n = blockIdx.y, chunk = blockIdx.x;
+    const int p0 = chunk * pix_per_chunk, p1 = min(HW, p0 + pix_per_chunk);
+    float sg[VEC], sgx[VEC], mu[VEC], is[VEC], mk[VEC];
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) {
+        sg[q] = 0.f; sgx[q] = 0.f;
+        const int c = col * VEC + q;
+        const bool ok = row < rows;
+        mu[q] = ok ? mean[c] : 0.f; is[q] = ok ? invstd[c] : 0.f;
+        mk[q] = (ok && mask) ? mask[(long)n * C + c] : 1.f;
+    }
+    if (row < rows) {
+        const long ib = (long)n * HW;
+        for (int p = p0 + row; p < p1; p += rows) {
+            float g[VEC], xv[VEC], av[VEC];
+            if constexpr (VEC == 4) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(dy + (ib + p) * lddy + col * 4);
+                const f32x4 u = *reinterpret_cast<const f32x4*>(x + (ib + p) * ldx + col * 4);
+                g[0] = t[0]; g[1] = t[1]; g[2] = t[2]; g[3] = t[3];
+                xv[0] = u[0]; xv[1] = u[1]; xv[2] = u[2]; xv[3] = u[3];
+                if (act) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(act + (ib + p) * ldact + col * 4);
+                    av[0] = a[0]; av[1] = a[1]; av[2] = a[2]; av[3] = a[3];
+                }
+            } else {
+                g[0] = dy[(ib + p) * lddy + col]; xv[0] = x[(ib + p) * ldx + col];
+                if (act) av[0] = act[(ib + p) * ldact + col];
+            }
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) {
+                float gg = g[q];
+                if (act) gg = (av[q] > 0.f) ? gg * mk[q] : 0.f;
+                sg[q] += gg;
+                sgx[q] += gg * (xv[q] - mu[q]) * is[q];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+            sm[(row * C + col * VEC + q) * 2 + 0] = sg[q];
+            sm[(row * C + col * VEC + q) * 2 + 1] = sgx[q];
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += TPB) {
+        double a = 0, b = 0;
+        for (int r = 0; r < rows; ++r) { a += sm[(r * C + c) * 2]; b += sm[(r * C + c) * 2 + 1]; }
+        float* o = part + (((long)n * gridDim.x + chunk) * C + c) * 2;
+        o[0] = (float)a; o[1] = (float)b;
+    }
+}
+
+__global__ void bn_bwd_reduce_final(const float* __restrict__ part, int nparts, int C, float* __restrict__ sums) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double a = 0, b = 0;
+    for (int k = 0; k < nparts; ++k) { a += part[((long)k * C + c) * 2]; b += part[((long)k * C + c) * 2 + 1]; }
+    sums[c] = (float)a;        // dbeta  = sum g
+    sums[C + c] = (float)b;    // dgamma = sum g * xhat
+}
+
+template <int VEC>
+__global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ x,
+                                                           int ldx, const float* __restrict__ act, int ldact, float* __restrict__ dx,
+                                                           int lddx, long P, int HW, int C, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, const float* __restrict__ scale,
+                                                           const float* __restrict__ sums, const float* __restrict__ mask, float inv_m) {
+    const int cvec = C / VEC;
+    const long total = P * cvec;
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
+        const long p = i / cvec;
+        const int c = (int)(i - p * cvec) * VEC;
+        const int n = (int)(p / HW);
+        float g[VEC], xv[VEC], av[VEC];
+        if constexpr (VEC == 4) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(dy + p * lddy + c);
+            const f32x4 u = *reinterpret_cast<const f32x4*>(x + p * ldx + c);
+            g[0] = t[0]; g[1] = t[1]; g[2] = t[2]; g[3] = t[3];
+            xv[0] = u[0]; xv[1] = u[1]; xv[2] = u[2]; xv[3] = u[3];
+            if (act) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(act + p * ldact + c);
+                av[0] = a[0]; av[1] = a[1]; av[2] = a[2]; av[3] = a[3];
+            }
+        } else {
+            g[0] = dy[p * lddy + c]; xv[0] = x[p * ldx + c];
+            if (act) av[0] = act[p * ldact + c];
+        }
+        float r[VEC];
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+            float gg = g[q];
+            if (act) gg = (av[q] > 0.f) ? gg * (mask ? mask[(long)n * C + c + q] : 1.f) : 0.f;
+            const float xh = (xv[q] - mean[c + q]) * invstd[c + q];
+            r[q] = scale[c + q] * (gg - sums[c + q] * inv_m - xh * sums[C + c + q] * inv_m);
+        }
+        if constexpr (VEC == 4) {
+            f32x4 t = {r[0], r[1], r[2], r[3]};
+            *reinterpret_cast<f32x4*>(dx + p * lddx + c) = t;
+        } else dx[p * lddx + c] = r[0];
+    }
+}
+
+// per-channel plain sum over all pixels (bias gradients), reusing the partial->final structure
+template <int VEC>
+__global__ __launch_bounds__(TPB) void chan_sum_partial(const float* __restrict__ x, int ld, long P, int C, long pix_per_chunk,
+                                                        float* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int cvec = C / VEC, rows = TPB / cvec, tid = threadIdx.x;
+    const int col = tid % cvec, row = tid / cvec;
+    const long p0 = (long)blockIdx.x * pix_per_chunk;
+    const long p1 = p0 + pix_per_chunk < P ? p0 + pix_per_chunk : P;
+    float s[VEC];
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) s[q] = 0.f;
+    if (row < rows) {
+        for (long p = p0 + row; p < p1; p += rows) {
+            if constexpr (VEC == 4) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(x + p * ld + col * 4);
+                s[0] += t[0]; s[1] += t[1]; s[2] += t[2]; s[3] += t[3];
+            } else s[0] += x[p * ld + col];
+        }
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) sm[row * C + col * VEC + q] = s[q];
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += TPB) {
+        double a = 0;
+        for (int r = 0; r < rows; ++r) a += sm[r * C + c];
+        part[(long)blockIdx.x * C + c] = (float)a;
+    }
+}
+__global__ void chan_sum_final(const float* __restrict__ part, int nparts, int C, float* __restrict__ out, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double a = 0;
+    for (int k = 0; k < nparts; ++k) a += part[(long)k * C + c];
+    out[c] = accumulate ? out[c] + (float)a : (float)a;
+}
+
+inline int pick_chunks(int N, int HW, int C, int rows) {
+    // ~32 vector loads per thread; at least one pass of `rows` pixels per chunk
+    long per_img = ((long)HW * C + 32767) / 32768;
+    if (per_img < 1) per_img = 1;
+    if (per_img > 1024) per_img = 1024;
+    long maxc = (HW + rows - 1) / rows;
+    if (per_img > maxc) per_img = maxc;
+    return (int)per_img;
+}
+inline int ew_grid(long total_vec) {
+    long b = (total_vec + TPB - 1) / TPB;
+    if (b > 4096) b = 4096;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace
+
+#define REQ_VEC(C) RUNET_REQUIRE((C) >= 1 && (C) <= 1024 && ((C) % 4 == 0 || (C) == 1), "channels must be 1 or a multiple of 4, at most 1024")
+
+extern "C" long runet_reduce_workspace_floats(int n_img, int hw, int c) {
+    return (long)n_img * 1024L * c * 7 + 64;
+}
+
+extern "C" int runet_chan_stats(const float* x, int ld, int n_img, int hw, int c, float* workspace, float* mean_nc,
+                                float* m2_nc, float* max_nc, float* min_nc, int* imax_nc, int* imin_nc, int want_minmax,
+                                void* stream) {
+    RUNET_REQUIRE(x && workspace && mean_nc && m2_nc, "null pointer");
+    REQ_VEC(c);
+    RUNET_REQUIRE(n_img > 0 && hw > 0 && ld >= c, "bad shape");
+    RUNET_REQUIRE(!want_minmax || (max_nc && min_nc && imax_nc && imin_nc), "min/max outputs missing");
+    hipStream_t st = (hipStream_t)stream;
+    const int vec = (c % 4 == 0) ? 4 : 1;
+    const int cvec = c / vec, rows = TPB / cvec;
+    const int chunks = pick_chunks(n_img, hw, c, rows);
+    const int ppc = (hw + chunks - 1) / chunks;
+    const size_t lds = (size_t)rows * c * (want_minmax ? 7 : 3) * sizeof(float);
+    RUNET_REQUIRE(lds <= 64 * 1024, "LDS budget");
+    dim3 grid(chunks, n_img);
+#define LAUNCH_STATS(V, MM) hipLaunchKernelGGL((chan_stats_partial<V, MM>), grid, dim3(TPB), lds, st, x, ld, hw, c, ppc, workspace)
+    if (vec == 4) { if (want_minmax) LAUNCH_STATS(4, true); else LAUNCH_STATS(4, false); }
+    else { if (want_minmax) LAUNCH_STATS(1, true); else LAUNCH_STATS(1, false); }
+#undef LAUNCH_STATS
+    const int tot = n_img * c;
+    if (want_minmax)
+        hipLaunchKernelGGL((chan_stats_combine<true>), dim3(cdiv(tot, 128)), dim3(128), 0, st, workspace, n_img, c, chunks, mean_nc, m2_nc, max_nc, min_nc, imax_nc, imin_nc);
+    else
+        hipLaunchKernelGGL((chan_stats_combine<false>), dim3(cdiv(tot, 128)), dim3(128), 0, st, workspace, n_img, c, chunks, mean_nc, m2_nc, nullptr, nullptr, nullptr, nullptr);
+    RUNET_CHECK_LAUNCH();
+}
+
+extern "C" int runet_bn_finalize(const float* mean_nc, const float* m2_nc, int n_img, int c, long hw, const float* gamma,
+                                 const float* beta, float* run_mean, float* run_var, long long* num_batches_tracked,
+                                 float momentum, float eps, int training, float* scale, float* shift, float* save_mean,
+                                 float* save_invstd, void* stream) {
+    RUNET_REQUIRE(scale && shift && c > 0, "null output");
+    RUNET_REQUIRE(training ? (mean_nc && m2_nc && (long)n_img * hw > 1) : (run_mean && run_var), "missing statistics (training needs > 1 value per channel)");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(c, 128)), dim3(128), 0, (hipStream_t)stream, mean_nc, m2_nc, n_img, c, hw,
+                       gamma, beta, run_mean, run_var, num_batches_tracked, momentum, eps, training, scale, shift, save_mean, save_invstd);
+    RUNET_CHECK_LAUNCH();
+}
+
+extern "C" int runet_bn_apply(const float* x, int ldx, float* y, int ldy, long pixels, int hw, int c, const float* scale,
+                              const float* shift, const float* mask_nc, int relu, void* stream) {
+    RUNET_REQUIRE(x && y && scale && shift, "null pointer");
+    REQ_VEC(c);
+    RUNET_REQUIRE(pixels > 0 && hw > 0 && ldx >= c && ldy >= c, "bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    if (c % 4 == 0) hipLaunchKernelGGL((bn_apply_kernel<4>), dim3(ew_grid(pixels * (c / 4))), dim3(TPB), 0, st, x, ldx, y, ldy, pixels, hw, c, scale, shift, mask_nc, relu);
+    else hipLaunchKernelGGL((bn_apply_kernel<1>), dim3(ew_grid(pixels * c)), dim3(TPB), 0, st, x, ldx, y, ldy, pixels, hw, c, scale, shift, mask_nc, relu);
+    RUNET_CHECK_LAUNCH();
+}
+
+extern "C" int runet_bn_bwd_reduce(const float* dy, int lddy, const float* x, int ldx, const float* act, int ldact, int n_img,
+                                   int hw, int c, const float* mean, const float* invstd, const float* mask_nc,
+                                   float* workspace, float* sums, void* stream) {
+    RUNET_REQUIRE(dy && x && mean && invstd && workspace && sums, "null pointer");
+    REQ_VEC(c);
+    hipStream_t st = (hipStream_t)stream;
+    const int vec = (c % 4 == 0) ? 4 : 1, cvec = c / vec, rows = TPB / cvec;
+    const int chunks = pick_chunks(n_img, hw, c, rows);
+    const int ppc = (hw + chunks - 1) / chunks;
+    const size_t lds = (size_t)rows * c * 2 * sizeof(float);
+    dim3 grid(chunks, n_img);
+    if (vec == 4) hipLaunchKernelGGL((bn_bwd_reduce_partial<4>), grid, dim3(TPB), lds, st, dy, lddy, x, ldx, act, ldact, hw, c, mean, invstd, mask_nc, ppc, workspace);
+    else hipLaunchKernelGGL((bn_bwd_reduce_partial<1>), grid, dim3(TPB), lds, st, dy, lddy, x, ldx, act, ldact, hw, c, mean, invstd, mask_nc, ppc, workspace);
+    hipLaunchKernelGGL(bn_bwd_reduce_final, dim3(cdiv(c, 128)), dim3(128), 0, st, workspace, chunks * n_img, c, sums);
+    RUNET_CHECK_LAUNCH();
+}
+
+extern "C" int runet_bn_bwd_apply(const float* dy, int lddy, const float* x, int ldx, const float* act, int ldact, float* dx,
+                                  int lddx, long pixels, int hw, int c, const float* mean, const float* invstd,
+                                  const float* scale, const float* sums, const float* mask_nc, void* stream) {
+    RUNET_REQUIRE(dy && x && dx && mean && invstd && scale && sums, "null pointer");
+    REQ_VEC(c);
+    hipStream_t st = (hipStream_t)stream;
+    const float inv_m = 1.0f / (float)pixels;
+    if (c % 4 == 0) hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3(ew_grid(pixels * (c / 4))), dim3(TPB), 0, st, dy, lddy, x, ldx, act, ldact, dx, lddx, pixels, hw, c, mean, invstd, scale, sums, mask_nc, inv_m);
+    else hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3(ew_grid(pixels * c)), dim3(TPB), 0, st, dy, lddy, x, ldx, act, ldact, dx, lddx, pixels, hw, c, mean, invstd, scale, sums, mask_nc, inv_m);
+    RUNET_CHECK_LAUNCH();
+}
+
+extern "C" int runet_chan_sum(const float* x, int ld, long pixels, int c, float* workspace, float* out, int accumulate, void* stream) {
+    RUNET_REQUIRE(x && workspace && out, "null pointer");
+    REQ_VEC(c);
+    hipStream_t st = (hipStream_t)stream;
+    const int vec = (c % 4 == 0) ? 4 : 1, cvec = c / vec, rows = TPB / cvec;
+    long chunks = (pixels * c + 32767) / 32768;
+    if (chunks > 2048) chunks = 2048;
+    if (chunks < 1) chunks = 1;
+    const long ppc = (pixels + chunks - 1) / chunks;
+    chunks = (pixels + ppc - 1) / ppc;
+    const size_t lds = (size_t)rows * c * sizeof(float);
+    if (vec == 4) hipLaunchKernelGGL((chan_sum_partial<4>), dim3((int)chunks), dim3(TPB), lds, st, x, ld, pixels, c, ppc, workspace);
+    else hipLaunchKernelGGL((chan_sum_partial<1>), dim3((int)chunks), dim3(TPB), lds, st, x, ld, pixels, c, ppc, workspace);
+    hipLaunchKernelGGL(chan_sum_final, dim3(cdiv(c, 128)), dim3(128), 0, st, workspace, (int)chunks, c, out, accumulate);
+    RUNET_CHECK_LAUNCH();
+}

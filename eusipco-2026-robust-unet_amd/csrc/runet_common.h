@@ -1,0 +1,51 @@
+// Shared helpers for the gfx950 Robust U-Net kernels (internal; the public C ABI is include/runet_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define RUNET_OK 0
+#define RUNET_EINVAL 1
+#define RUNET_ELAUNCH 2
+
+extern "C" void runet_set_error(const char* msg);
+
+#define RUNET_REQUIRE(cond, msg)                                          \
+    do {                                                                  \
+        if (!(cond)) {                                                    \
+            char _b[512];                                                 \
+            snprintf(_b, sizeof(_b), "%s: %s (%s)", __func__, msg, #cond); \
+            runet_set_error(_b);                                          \
+            return RUNET_EINVAL;                                          \
+        }                                                                 \
+    } while (0)
+
+#define RUNET_CHECK_LAUNCH()                                                   \
+    do {                                                                       \
+        hipError_t _e = hipGetLastError();                                     \
+        if (_e != hipSuccess) {                                                \
+            char _b[512];                                                      \
+            snprintf(_b, sizeof(_b), "%s: launch failed: %s", __func__, hipGetErrorString(_e)); \
+            runet_set_error(_b);                                               \
+            return RUNET_ELAUNCH;                                              \
+        }                                                                      \
+        return RUNET_OK;                                                       \
+    } while (0)
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- wave / block reductions (wave = 64 lanes) ----
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }

@@ -1,0 +1,122 @@
+"""Thin Python wrappers over the C ABI (include/runet_hip.h).
+
+Activations are torch tensors used purely as device-memory handles: logical shape
+[N, H, W, C] (NHWC), last-dim stride 1, pixel stride `ld = t.stride(2)` (a tensor may be a
+channel slice of a wider concat buffer).  All launches go to torch's current HIP stream.
+"""
+from __future__ import annotations
+
+import torch
+
+from ._lib import check, lib
+
+CONV_FWD, CONV_DGRAD, CONVT_FWD, CONVT_DGRAD = 0, 1, 2, 3
+
+_ws = {}
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ld(t):
+    """Pixel stride of an NHWC view; validates the layout contract."""
+    n, h, w, c = t.shape
+    s = t.stride()
+    if not (s[3] == 1 and s[1] == w * s[2] and (n == 1 or s[0] == h * w * s[2]) and s[2] >= c):
+        raise ValueError(f"not an NHWC (slice) view: shape {tuple(t.shape)} strides {s}")
+    return s[2]
+
+
+def empty_nhwc(n, h, w, c, like):
+    return torch.empty((n, h, w, c), device=like.device, dtype=torch.float32)
+
+
+def workspace(nfloats, device):
+    key = (device.index, "wgrad")
+    buf = _ws.get(key)
+    if buf is None or buf.numel() < nfloats:
+        buf = torch.empty(max(nfloats, 1 << 22), device=device, dtype=torch.float32)
+        _ws[key] = buf
+    return buf
+
+
+def hwio(w):
+    """Physical [kh, kw, cin, cout] view of a conv weight stored the way model.py stores it
+    (logical OIHW tensor whose memory is HWIO); falls back to a copy for foreign layouts."""
+    v = w.permute(2, 3, 1, 0)
+    return v if v.is_contiguous() else v.contiguous()
+
+
+def hwio_t(w):
+    """ConvTranspose2d weight (logical [cin, cout, 2, 2]) -> physical [2, 2, cin, cout]."""
+    v = w.permute(2, 3, 0, 1)
+    return v if v.is_contiguous() else v.contiguous()
+
+
+def conv_fwd(x, w_hwio, bias=None, out=None, dil=1, accumulate=False):
+    n, h, w, cin = x.shape
+    kh, kw, cin_w, cout = w_hwio.shape
+    if out is None:
+        out = empty_nhwc(n, h, w, cout, x)
+    check(lib.runet_conv_igemm(x.data_ptr(), ld(x), w_hwio.data_ptr(), bias.data_ptr() if bias is not None else None,
+                               out.data_ptr(), ld(out), n, h, w, cin, cin_w, cout, kh, kw, dil, CONV_FWD,
+                               int(accumulate), stream()))
+    return out
+
+
+def conv_dgrad(dy, w_hwio, out=None, dil=1, accumulate=False):
+    n, h, w, cout = dy.shape
+    kh, kw, cin, cout_w = w_hwio.shape
+    assert cout_w == cout
+    if out is None:
+        out = empty_nhwc(n, h, w, cin, dy)
+    check(lib.runet_conv_igemm(dy.data_ptr(), ld(dy), w_hwio.data_ptr(), None, out.data_ptr(), ld(out), n, h, w,
+                               cout, cout, cin, kh, kw, dil, CONV_DGRAD, int(accumulate), stream()))
+    return out
+
+
+def conv_wgrad(x, dy, kh, kw, cin_w=None, dil=1, out=None):
+    n, h, w, cin = x.shape
+    cout = dy.shape[3]
+    cin_w = cin if cin_w is None else cin_w
+    if out is None:
+        out = torch.empty((kh, kw, cin_w, cout), device=x.device, dtype=torch.float32)
+    nws = lib.runet_conv_wgrad_workspace_floats(n, h, w, cin_w, cout, kh, kw)
+    ws = workspace(nws, x.device)
+    check(lib.runet_conv_wgrad(x.data_ptr(), ld(x), dy.data_ptr(), ld(dy), out.data_ptr(), ws.data_ptr(), ws.numel(),
+                               n, h, w, cin, cin_w, cout, kh, kw, dil, 0, stream()))
+    return out
+
+
+def convt_fwd(x, w_hwio, bias=None, out=None):
+    n, h, w, cin = x.shape
+    _, _, cin_w, cout = w_hwio.shape
+    if out is None:
+        out = empty_nhwc(n, 2 * h, 2 * w, cout, x)
+    check(lib.runet_conv_igemm(x.data_ptr(), ld(x), w_hwio.data_ptr(), bias.data_ptr() if bias is not None else None,
+                               out.data_ptr(), ld(out), n, h, w, cin, cin_w, cout, 2, 2, 1, CONVT_FWD, 0, stream()))
+    return out
+
+
+def convt_dgrad(dy, w_hwio, out=None, accumulate=False):
+    n, h2, w2, cout = dy.shape
+    _, _, cin, cout_w = w_hwio.shape
+    h, w = h2 // 2, w2 // 2
+    if out is None:
+        out = empty_nhwc(n, h, w, cin, dy)
+    check(lib.runet_conv_igemm(dy.data_ptr(), ld(dy), w_hwio.data_ptr(), None, out.data_ptr(), ld(out), n, h, w,
+                               cout, cout, cin, 2, 2, 1, CONVT_DGRAD, int(accumulate), stream()))
+    return out
+
+
+def convt_wgrad(x, dy, out=None):
+    n, h, w, cin = x.shape
+    cout = dy.shape[3]
+    if out is None:
+        out = torch.empty((2, 2, cin, cout), device=x.device, dtype=torch.float32)
+    nws = lib.runet_conv_wgrad_workspace_floats(n, h, w, cin, cout, 2, 2)
+    ws = workspace(nws, x.device)
+    check(lib.runet_conv_wgrad(x.data_ptr(), ld(x), dy.data_ptr(), ld(dy), out.data_ptr(), ws.data_ptr(), ws.numel(),
+                               n, h, w, cin, cin, cout, 2, 2, 1, 1, stream()))
+    return out

@@ -1,0 +1,124 @@
+"""GPU parity: implicit-GEMM convolutions (fwd / dgrad / wgrad / transposed) through the C ABI
+vs stock torch CPU fp32 ops on the same seeded inputs.  Tolerance: fp32 MFMA accumulates in a
+different order than oneDNN, so |err| <= 2e-4 * (1 + |ref|) on O(1) data with K <= 9216."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+prng = importlib.import_module("eusipco-2026-robust-unet_amd.portable_rng")
+
+
+def _ops():
+    return importlib.import_module("eusipco-2026-robust-unet_amd.ops")
+
+
+def rnd(shape, seed, std=1.0):
+    return torch.from_numpy(prng.normal_f32(shape, seed, std))
+
+
+def close(a, b, tol=2e-4):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    err = (a - b).abs()
+    lim = tol * (1.0 + b.abs())
+    assert bool((err <= lim).all()), f"max err {err.max().item():.3e} (ref max {b.abs().max().item():.3e})"
+
+
+CASES = [
+    # n, h, w, cin, cout, k, dil
+    (2, 8, 8, 16, 32, 3, 1),
+    (2, 16, 16, 32, 64, 3, 1),
+    (1, 12, 20, 64, 128, 3, 1),      # non-square, tile tails
+    (2, 16, 16, 32, 16, 3, 2),       # dilation 2, narrow cout
+    (2, 16, 16, 32, 48, 3, 4),       # dilation 4, cout not a multiple of 32
+    (3, 4, 4, 128, 256, 3, 1),       # tiny spatial (config-1 bottleneck)
+    (2, 16, 16, 64, 32, 1, 1),       # 1x1
+    (2, 8, 8, 256, 8, 1, 1),         # 1x1, cout 8
+    (1, 64, 64, 64, 64, 3, 1),       # 256x64 tile path (P = 4096 < threshold) and more
+    (2, 256, 256, 16, 64, 3, 1),     # large M: 256-row tiles
+]
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout,k,dil", CASES)
+def test_conv_fwd_dgrad_wgrad(n, h, w, cin, cout, k, dil):
+    ops = _ops()
+    dev = torch.device("cuda:0")
+    x = rnd((n, cin, h, w), 1)
+    wt = rnd((cout, cin, k, k), 2, std=(2.0 / (cin * k * k)) ** 0.5)
+    b = rnd((cout,), 3)
+    gy = rnd((n, cout, h, w), 4)
+    xr = x.clone().requires_grad_(True)
+    wr = wt.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, b, padding=dil * (k // 2), dilation=dil)
+    yr.backward(gy)
+
+    xg = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    wg = wt.permute(2, 3, 1, 0).contiguous().to(dev)      # HWIO
+    gyg = gy.permute(0, 2, 3, 1).contiguous().to(dev)
+    y = ops.conv_fwd(xg, wg, b.to(dev), dil=dil)
+    close(y.permute(0, 3, 1, 2), yr)
+    dx = ops.conv_dgrad(gyg, wg, dil=dil)
+    close(dx.permute(0, 3, 1, 2), xr.grad)
+    dw = ops.conv_wgrad(xg, gyg, k, k, dil=dil)
+    close(dw.permute(3, 2, 0, 1), wr.grad, tol=3e-4 * max(1.0, (n * h * w / 256.0) ** 0.5))
+    # accumulate + channel-slice destination (concat buffer)
+    buf = torch.full((n, h, w, cout + 16), 7.0, device=dev)
+    ops.conv_fwd(xg, wg, None, out=buf[..., 16:], dil=dil, accumulate=True)
+    close(buf[..., 16:].permute(0, 3, 1, 2), yr - b.view(1, -1, 1, 1) + 7.0)
+    assert float(buf[..., :16].min()) == 7.0 and float(buf[..., :16].max()) == 7.0
+
+
+def test_conv_stem_rgb_padded_to_4():
+    """Cin = 3 stem: x zero-padded to 4 channels, weight keeps its 3 rows (cin_w = 3)."""
+    ops = _ops()
+    dev = torch.device("cuda:0")
+    n, h, w, cout = 2, 32, 32, 64
+    x = rnd((n, 3, h, w), 5)
+    wt = rnd((cout, 3, 3, 3), 6, std=0.2)
+    gy = rnd((n, cout, h, w), 7)
+    wr = wt.clone().requires_grad_(True)
+    yr = F.conv2d(x, wr, None, padding=1)
+    yr.backward(gy)
+    xp = torch.zeros((n, h, w, 4))
+    xp[..., :3] = x.permute(0, 2, 3, 1)
+    xg = xp.to(dev)
+    wg = wt.permute(2, 3, 1, 0).contiguous().to(dev)
+    close(ops.conv_fwd(xg, wg).permute(0, 3, 1, 2), yr)
+    dw = ops.conv_wgrad(xg, gy.permute(0, 2, 3, 1).contiguous().to(dev), 3, 3, cin_w=3)
+    assert tuple(dw.shape) == (3, 3, 3, cout)
+    close(dw.permute(3, 2, 0, 1), wr.grad, tol=5e-4)
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout", [(2, 4, 4, 64, 32), (1, 16, 16, 128, 64), (2, 8, 8, 32, 16)])
+def test_conv_transpose_k2s2(n, h, w, cin, cout):
+    ops = _ops()
+    dev = torch.device("cuda:0")
+    x = rnd((n, cin, h, w), 8)
+    wt = rnd((cin, cout, 2, 2), 9, std=(1.0 / cin) ** 0.5)
+    b = rnd((cout,), 10)
+    gy = rnd((n, cout, 2 * h, 2 * w), 11)
+    xr, wr = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+    yr = F.conv_transpose2d(xr, wr, b, stride=2)
+    yr.backward(gy)
+    xg = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    wg = wt.permute(2, 3, 0, 1).contiguous().to(dev)      # [2,2,cin,cout]
+    gyg = gy.permute(0, 2, 3, 1).contiguous().to(dev)
+    buf = torch.zeros((n, 2 * h, 2 * w, 2 * cout), device=dev)
+    ops.convt_fwd(xg, wg, b.to(dev), out=buf[..., cout:])          # right half of a concat buffer
+    close(buf[..., cout:].permute(0, 3, 1, 2), yr)
+    assert float(buf[..., :cout].abs().max()) == 0.0
+    close(ops.convt_dgrad(gyg, wg).permute(0, 3, 1, 2), xr.grad)
+    close(ops.convt_wgrad(xg, gyg).permute(2, 3, 0, 1), wr.grad, tol=5e-4)
+
+
+def test_conv_rejects_bad_shapes():
+    ops = _ops()
+    dev = torch.device("cuda:0")
+    x = torch.zeros((1, 4, 4, 6), device=dev)           # cin not a multiple of 4
+    w = torch.zeros((3, 3, 6, 16), device=dev)
+    with pytest.raises(RuntimeError):
+        ops.conv_fwd(x, w)
