@@ -1,4 +1,5 @@
-"""ctypes binding of csrc/librunet_hip.so (C ABI declared in include/runet_hip.h).
+"""ctypes binding of csrc/librunet_hip.so; prototypes are read from include/runet_hip.h so the
+binding cannot drift from the declared C ABI.
 
 There is no fallback: if the shared library is missing or fails to load, importing this
 module raises, and every op in the package is unusable (the product path never routes
@@ -8,9 +9,42 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "librunet_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "runet_hip.h")
+
+_SCALARS = {"int": C.c_int, "long": C.c_long, "float": C.c_float, "double": C.c_double, "void": None}
+
+
+def _ctype(decl: str):
+    decl = decl.strip()
+    if "*" in decl:
+        return C.c_char_p if decl.replace(" ", "") == "constchar*" else C.c_void_p
+    base = decl.replace("const", "").split()
+    return _SCALARS[base[0]]
+
+
+def parse_header(path: str = HEADER_PATH):
+    """-> {name: (restype, [argtypes])} for every function declared in the header."""
+    text = open(path).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"^\s*((?:const\s+)?(?:char\*|char \*|int|long|void|float|double))\s+(\w+)\s*\(([^;{]*?)\)\s*;", text, re.M | re.S):
+        ret, name, args = m.group(1), m.group(2), " ".join(m.group(3).split())
+        argtypes = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                # drop the parameter name (last identifier) unless the declaration ends with '*'
+                t = a if a.endswith("*") else a.rsplit(" ", 1)[0]
+                if "*" in a:
+                    t = a[: a.rindex("*") + 1]
+                argtypes.append(_ctype(t))
+        protos[name] = (_ctype(ret), argtypes)
+    return protos
+
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -19,57 +53,11 @@ if not os.path.exists(LIB_PATH):
         "There is no CPU fallback for the Robust U-Net kernels.")
 
 lib = C.CDLL(LIB_PATH)
-
-P, I, L, F, D = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double
-
-_SIGS = {
-    "runet_abi_version": (I, []),
-    "runet_conv_igemm": (I, [P, I, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P]),
-    "runet_conv_wgrad_workspace_floats": (L, [I, I, I, I, I, I, I]),
-    "runet_conv_wgrad": (I, [P, I, P, I, P, P, L, I, I, I, I, I, I, I, I, I, I, P]),
-    "runet_chan_stats": (I, [P, I, I, I, I, P, P, P, P, P, P, I, P]),
-    "runet_bn_finalize": (I, [P, P, I, I, L, P, P, P, P, F, F, I, P, P, P, P, P]),
-    "runet_bn_apply": (I, [P, I, P, I, L, I, I, P, P, P, I, P]),
-    "runet_bn_bwd_reduce": (I, [P, I, P, I, P, I, P, I, I, I, P, P, P, P, I, P]),
-    "runet_bn_bwd_finalize": (I, [P, I, I, L, P, P, P, P, P, P]),
-    "runet_bn_bwd_apply": (I, [P, I, P, I, P, I, P, P, I, I, I, P, P, P, P, I, P]),
-    "runet_maxpool2_fwd": (I, [P, I, P, I, P, I, I, I, I, P]),
-    "runet_maxpool2_bwd": (I, [P, I, P, P, I, I, I, I, I, I, P]),
-    "runet_nchw_to_nhwc_pad": (I, [P, P, I, I, I, I, P]),
-    "runet_ca_coeff": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, P, P, P, P, P, P, P, P, P]),
-    "runet_sa_reduce": (I, [P, I, P, P, I, I, I, P, P, P]),
-    "runet_sa_conv7": (I, [P, P, P, I, I, I, P]),
-    "runet_rb_out": (I, [P, I, P, P, P, P, I, P, P, P, I, I, I, I, P]),
-    "runet_rb_bwd1": (I, [P, I, P, I, P, I, P, P, P, P, I, P, I, I, I, P]),
-    "runet_sa_conv7_bwd": (I, [P, P, P, P, P, P, I, I, I, P]),
-    "runet_rb_bwd2": (I, [P, I, P, I, P, P, P, P, I, I, I, P, P, P, I, P]),
-    "runet_ca_bwd_coeff": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P, P, P, P, P, P, P, P, P]),
-    "runet_rb_bwd3": (I, [P, I, P, I, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P]),
-    "runet_ag_psi": (I, [P, I, P, I, P, P, P, P, P, P, P, L, I, P]),
-    "runet_ag_out": (I, [P, I, P, P, P, P, I, L, I, P]),
-    "runet_ag_bwd1": (I, [P, I, P, I, P, P, P, P, I, P, L, I, P]),
-    "runet_ag_bwd2": (I, [P, P, I, P, I, P, P, P, P, P, P, I, P, P, L, I, I, P]),
-    "runet_outc_fwd": (I, [P, I, P, P, P, P, L, I, P]),
-    "runet_outc_bwd": (I, [P, P, P, I, P, P, I, P, P, L, I, I, P]),
-    "runet_bce_fwd": (I, [P, P, P, L, I, P]),
-    "runet_bce_finalize": (I, [P, I, L, P, P]),
-    "runet_bce_bwd": (I, [P, P, P, P, L, P]),
-    "runet_adam_multi": (I, [P, I, L, I, F, F, F, F, F, F, F, P]),
-    "runet_seg_counts": (I, [P, P, P, I, L, F, P]),
-    "runet_fill": (I, [P, F, L, P]),
-    "runet_axpy": (I, [P, P, F, L, P]),
-    "runet_chan_sum": (I, [P, I, L, I, P, P, I, P]),
-}
-
-for _name, (_res, _args) in _SIGS.items():
-    try:
-        _fn = getattr(lib, _name)
-    except AttributeError:
-        continue  # checked by tests/test_abi.py against include/runet_hip.h
+PROTOS = parse_header()
+for _name, (_res, _args) in PROTOS.items():
+    _fn = getattr(lib, _name)      # AttributeError here = header declares a symbol the library lacks
     _fn.restype = _res
     _fn.argtypes = _args
-
-lib.runet_last_error.restype = C.c_char_p
 
 
 def check(rc: int):

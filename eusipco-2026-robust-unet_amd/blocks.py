@@ -1,0 +1,431 @@
+"""Forward / backward of the Robust U-Net building blocks as explicit kernel sequences.
+
+Every function here takes NHWC fp32 device tensors (see ops.ld) and calls the C ABI directly;
+the backward functions consume the context returned by the matching forward.  No autograd,
+no torch compute ops: torch only allocates device memory.  model.py wraps these in
+autograd.Functions so that `loss.backward()` on the drop-in nn.Module works.
+
+Reference semantics: /root/reference/Main_Final.py ResidualBlock :151-196, DilatedBlock :199-223,
+AttentionGate :120-148 + ConvTranspose2d + torch.cat :301-303, outc :274-277, MaxPool2d :235.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from ._lib import check, lib
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+class Small:
+    """Carves small per-channel scratch vectors out of pooled device buffers (fewer allocator calls)."""
+
+    CHUNK = 1 << 16
+
+    def __init__(self, device):
+        self.device = device
+        self.buf = None
+        self.off = 0
+
+    def _take(self, n, dtype):
+        n4 = (n + 3) // 4 * 4
+        if n4 > self.CHUNK:
+            return torch.empty(n, device=self.device, dtype=dtype)
+        if self.buf is None or self.off + n4 > self.CHUNK:
+            self.buf = torch.empty(self.CHUNK, device=self.device, dtype=torch.float32)
+            self.off = 0
+        t = self.buf[self.off:self.off + n]
+        self.off += n4
+        return t if dtype == torch.float32 else t.view(dtype)
+
+    def f(self, n):
+        return self._take(n, torch.float32)
+
+    def i(self, n):
+        return self._take(n, torch.int32)
+
+
+_scratch = {}
+
+
+def scratch(nfloats, device):
+    """Per-device reduction workspace (partials); grows monotonically."""
+    buf = _scratch.get(device.index)
+    if buf is None or buf.numel() < nfloats:
+        buf = torch.empty(max(int(nfloats), 1 << 21), device=device, dtype=torch.float32)
+        _scratch[device.index] = buf
+    return buf
+
+
+def _ws(n, hw, c, device):
+    return scratch(lib.runet_reduce_workspace_floats(n, hw, c), device)
+
+
+class BNState:
+    """Physical handles of one BatchNorm2d (parameters + buffers)."""
+    __slots__ = ("weight", "bias", "running_mean", "running_var", "nbt")
+
+    def __init__(self, weight, bias, running_mean, running_var, nbt):
+        self.weight, self.bias, self.running_mean, self.running_var, self.nbt = weight, bias, running_mean, running_var, nbt
+
+
+def bn_coeff(x, bn: BNState, training, sm: Small, want_minmax=False, stats_hook=None):
+    """Batch (training) or running (eval) statistics -> (scale, shift, save_mean, save_invstd[, per-(n,c) stats])."""
+    n, h, w, c = x.shape
+    hw = h * w
+    st = ops.stream()
+    scale, shift, mean, invstd = sm.f(c), sm.f(c), sm.f(c), sm.f(c)
+    nc = None
+    if training or want_minmax:
+        mean_nc, m2_nc = sm.f(n * c), sm.f(n * c)
+        if want_minmax:
+            max_nc, min_nc, imax, imin = sm.f(n * c), sm.f(n * c), sm.i(n * c), sm.i(n * c)
+            nc = (mean_nc, m2_nc, max_nc, min_nc, imax, imin)
+        ws = _ws(n, hw, c, x.device)
+        check(lib.runet_chan_stats(x.data_ptr(), ops.ld(x), n, hw, c, ws.data_ptr(), mean_nc.data_ptr(), m2_nc.data_ptr(),
+                                   nc[2].data_ptr() if nc else None, nc[3].data_ptr() if nc else None,
+                                   nc[4].data_ptr() if nc else None, nc[5].data_ptr() if nc else None, int(want_minmax), st))
+        if stats_hook is not None and training:   # SyncBN: merge (mean, M2) across ranks before finalising
+            mean_nc, m2_nc, n_eff = stats_hook(mean_nc, m2_nc, n, hw, c)
+        else:
+            n_eff = n
+    if training:
+        check(lib.runet_bn_finalize(mean_nc.data_ptr(), m2_nc.data_ptr(), n_eff, c, hw, bn.weight.data_ptr(), bn.bias.data_ptr(),
+                                    bn.running_mean.data_ptr(), bn.running_var.data_ptr(), bn.nbt.data_ptr(), BN_MOMENTUM, BN_EPS, 1,
+                                    scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), st))
+    else:
+        check(lib.runet_bn_finalize(None, None, n, c, hw, bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
+                                    bn.running_var.data_ptr(), None, BN_MOMENTUM, BN_EPS, 0, scale.data_ptr(), shift.data_ptr(),
+                                    mean.data_ptr(), invstd.data_ptr(), st))
+    return scale, shift, mean, invstd, nc
+
+
+def bn_apply(x, scale, shift, mask=None, relu=False, out=None):
+    n, h, w, c = x.shape
+    if out is None:
+        out = ops.empty_nhwc(n, h, w, c, x)
+    check(lib.runet_bn_apply(x.data_ptr(), ops.ld(x), out.data_ptr(), ops.ld(out), n * h * w, h * w, c, scale.data_ptr(), shift.data_ptr(),
+                             mask.data_ptr() if mask is not None else None, int(relu), ops.stream()))
+    return out
+
+
+def bn_backward(dy, x, mean, invstd, scale, sm: Small, act=None, mask=None, out=None, m_total=None):
+    """-> (dx, sums) with sums[:c] = dbeta, sums[c:] = dgamma.  act/mask: fused relu(+dropout) backward."""
+    n, h, w, c = x.shape
+    hw = h * w
+    st = ops.stream()
+    sums = sm.f(2 * c)
+    ws = _ws(n, hw, c, x.device)
+    actp, lda = (act.data_ptr(), ops.ld(act)) if act is not None else (None, 0)
+    maskp = mask.data_ptr() if mask is not None else None
+    check(lib.runet_bn_bwd_reduce(dy.data_ptr(), ops.ld(dy), x.data_ptr(), ops.ld(x), actp, lda, n, hw, c, mean.data_ptr(), invstd.data_ptr(),
+                                  maskp, ws.data_ptr(), sums.data_ptr(), st))
+    if out is None:
+        out = ops.empty_nhwc(n, h, w, c, x)
+    check(lib.runet_bn_bwd_apply(dy.data_ptr(), ops.ld(dy), x.data_ptr(), ops.ld(x), actp, lda, out.data_ptr(), ops.ld(out), n * hw, hw, c,
+                                 mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), sums.data_ptr(), maskp, st))
+    return out, sums
+
+
+def chan_sum(x, sm: Small):
+    n, h, w, c = x.shape
+    out = sm.f(c)
+    ws = _ws(n, h * w, c, x.device)
+    check(lib.runet_chan_sum(x.data_ptr(), ops.ld(x), n * h * w, c, ws.data_ptr(), out.data_ptr(), 0, ops.stream()))
+    return out
+
+
+# =============================================================================== ResidualBlock
+class RBParams:
+    __slots__ = ("w1", "bn1", "w2", "bn2", "w0p", "w2p", "wsa", "ws", "bns", "cin_w")
+
+    def __init__(self, w1, bn1, w2, bn2, w0p, w2p, wsa, ws=None, bns=None):
+        self.w1, self.bn1, self.w2, self.bn2, self.w0p, self.w2p, self.wsa, self.ws, self.bns = w1, bn1, w2, bn2, w0p, w2p, wsa, ws, bns
+        self.cin_w = w1.shape[2]
+
+
+def rb_forward(x, p: RBParams, training, mask=None, save=True, stats_hook=None):
+    """x: [N,H,W,Cx] with Cx >= cin_w (stem: RGB zero-padded to 4).  -> (out [N,H,W,C], ctx or None)"""
+    n, h, w, _ = x.shape
+    c = p.w1.shape[3]
+    cr = p.w0p.shape[3]
+    hw, P = h * w, n * h * w
+    st = ops.stream()
+    sm = Small(x.device)
+    if p.ws is not None:
+        r = ops.conv_fwd(x, p.ws)
+        ss, hs, mean_s, invstd_s, _ = bn_coeff(r, p.bns, training, sm, stats_hook=stats_hook)
+    else:
+        r, ss, hs, mean_s, invstd_s = x, None, None, None, None
+    t1 = ops.conv_fwd(x, p.w1)
+    s1, h1, mean1, invstd1, _ = bn_coeff(t1, p.bn1, training, sm, stats_hook=stats_hook)
+    use_mask = mask if training else None
+    a1 = bn_apply(t1, s1, h1, use_mask, relu=True)
+    if not save:
+        del t1
+    t2 = ops.conv_fwd(a1, p.w2)
+    s2, h2, mean2, invstd2, nc = bn_coeff(t2, p.bn2, training, sm, want_minmax=True, stats_hook=stats_hook)
+    mean_nc, _, max_nc, min_nc, imax, imin = nc
+    A, B, ca, avg, mx, tval = (sm.f(n * c) for _ in range(6))
+    idx = sm.i(n * c)
+    check(lib.runet_ca_coeff(mean_nc.data_ptr(), max_nc.data_ptr(), min_nc.data_ptr(), imax.data_ptr(), imin.data_ptr(), s2.data_ptr(),
+                             h2.data_ptr(), p.w0p.data_ptr(), p.w2p.data_ptr(), n, c, cr, A.data_ptr(), B.data_ptr(), ca.data_ptr(),
+                             avg.data_ptr(), mx.data_ptr(), idx.data_ptr(), tval.data_ptr(), st))
+    smap = torch.empty((P, 2), device=x.device, dtype=torch.float32)
+    amax = torch.empty(P, device=x.device, dtype=torch.int32)
+    check(lib.runet_sa_reduce(t2.data_ptr(), ops.ld(t2), A.data_ptr(), B.data_ptr(), P, hw, c, smap.data_ptr(), amax.data_ptr(), st))
+    sa = torch.empty(P, device=x.device, dtype=torch.float32)
+    check(lib.runet_sa_conv7(smap.data_ptr(), p.wsa.data_ptr(), sa.data_ptr(), n, h, w, st))
+    out = ops.empty_nhwc(n, h, w, c, x)
+    check(lib.runet_rb_out(t2.data_ptr(), ops.ld(t2), A.data_ptr(), B.data_ptr(), sa.data_ptr(), r.data_ptr(), ops.ld(r),
+                           ss.data_ptr() if ss is not None else None, hs.data_ptr() if hs is not None else None, out.data_ptr(),
+                           ops.ld(out), P, hw, c, st))
+    if not save:
+        return out, None
+    ctx = dict(x=x, r=r, t1=t1, a1=a1, t2=t2, out=out, mask=use_mask, p=p, s1=s1, mean1=mean1, invstd1=invstd1, s2=s2, h2=h2,
+               mean2=mean2, invstd2=invstd2, ss=ss, mean_s=mean_s, invstd_s=invstd_s, A=A, B=B, ca=ca, avg=avg, mx=mx, idx=idx,
+               tval=tval, mean_nc=mean_nc, smap=smap, amax=amax, sa=sa)
+    return out, ctx
+
+
+def rb_backward(ctx, dout, need_dx=True):
+    """-> (dx or None, grads dict keyed like the module's parameters, physical layouts)."""
+    p: RBParams = ctx["p"]
+    x, r, t1, a1, t2, out = ctx["x"], ctx["r"], ctx["t1"], ctx["a1"], ctx["t2"], ctx["out"]
+    n, h, w, c = out.shape
+    cr = p.w0p.shape[3]
+    hw, P = h * w, n * h * w
+    st = ops.stream()
+    dev = x.device
+    sm = Small(dev)
+    A, B, sa, smap, amax = ctx["A"], ctx["B"], ctx["sa"], ctx["smap"], ctx["amax"]
+    g = {}
+    dv = ops.empty_nhwc(n, h, w, c, x)
+    dq = torch.empty(P, device=dev, dtype=torch.float32)
+    check(lib.runet_rb_bwd1(dout.data_ptr(), ops.ld(dout), out.data_ptr(), ops.ld(out), t2.data_ptr(), ops.ld(t2), A.data_ptr(), B.data_ptr(),
+                            sa.data_ptr(), dv.data_ptr(), ops.ld(dv), dq.data_ptr(), P, hw, c, st))
+    dsm = torch.empty((P, 2), device=dev, dtype=torch.float32)
+    dwsa = torch.empty((7, 7, 2, 1), device=dev, dtype=torch.float32)
+    ws = scratch(lib.runet_sa_conv7_bwd_workspace_floats(n, h, w), dev)
+    check(lib.runet_sa_conv7_bwd(smap.data_ptr(), dq.data_ptr(), p.wsa.data_ptr(), dsm.data_ptr(), dwsa.data_ptr(), ws.data_ptr(), n, h, w, st))
+    g["sa.conv1.weight"] = dwsa
+    sdu, sdut = sm.f(n * c), sm.f(n * c)
+    ws = _ws(n, hw, c, dev)
+    check(lib.runet_rb_bwd2(dv.data_ptr(), ops.ld(dv), t2.data_ptr(), ops.ld(t2), sa.data_ptr(), dsm.data_ptr(), amax.data_ptr(), n, hw, c,
+                            ws.data_ptr(), sdu.data_ptr(), sdut.data_ptr(), st))
+    davg, dmx, sums2 = sm.f(n * c), sm.f(n * c), sm.f(2 * c)
+    dw0p = torch.empty((1, 1, c, cr), device=dev, dtype=torch.float32)
+    dw2p = torch.empty((1, 1, cr, c), device=dev, dtype=torch.float32)
+    ws = scratch(lib.runet_ca_bwd_workspace_floats(n, c, cr), dev)
+    check(lib.runet_ca_bwd(sdu.data_ptr(), sdut.data_ptr(), ctx["s2"].data_ptr(), ctx["h2"].data_ptr(), ctx["ca"].data_ptr(),
+                           ctx["avg"].data_ptr(), ctx["mx"].data_ptr(), p.w0p.data_ptr(), p.w2p.data_ptr(), ctx["mean_nc"].data_ptr(),
+                           ctx["tval"].data_ptr(), ctx["mean2"].data_ptr(), ctx["invstd2"].data_ptr(), n, c, cr, ws.data_ptr(),
+                           davg.data_ptr(), dmx.data_ptr(), sums2.data_ptr(), dw0p.data_ptr(), dw2p.data_ptr(), st))
+    g["ca.fc.0.weight"], g["ca.fc.2.weight"] = dw0p, dw2p
+    g["bn2.bias"], g["bn2.weight"] = sums2[:c], sums2[c:]
+    dt2 = ops.empty_nhwc(n, h, w, c, x)
+    check(lib.runet_rb_bwd3(dv.data_ptr(), ops.ld(dv), t2.data_ptr(), ops.ld(t2), sa.data_ptr(), dsm.data_ptr(), amax.data_ptr(),
+                            ctx["ca"].data_ptr(), davg.data_ptr(), dmx.data_ptr(), ctx["idx"].data_ptr(), ctx["mean2"].data_ptr(),
+                            ctx["invstd2"].data_ptr(), ctx["s2"].data_ptr(), sums2.data_ptr(), dt2.data_ptr(), ops.ld(dt2), P, hw, c, st))
+    g["conv2.weight"] = ops.conv_wgrad(a1, dt2, 3, 3)
+    da1 = ops.conv_dgrad(dt2, p.w2)
+    del dt2
+    dt1, sums1 = bn_backward(da1, t1, ctx["mean1"], ctx["invstd1"], ctx["s1"], sm, act=a1, mask=ctx["mask"], out=da1)
+    g["bn1.bias"], g["bn1.weight"] = sums1[:c], sums1[c:]
+    g["conv1.weight"] = ops.conv_wgrad(x, dt1, 3, 3, cin_w=p.cin_w)
+    dx = None
+    if p.ws is not None:
+        dr, sums_s = bn_backward(dv, r, ctx["mean_s"], ctx["invstd_s"], ctx["ss"], sm, out=dv)
+        g["shortcut.1.bias"], g["shortcut.1.weight"] = sums_s[:c], sums_s[c:]
+        g["shortcut.0.weight"] = ops.conv_wgrad(x, dr, 1, 1, cin_w=p.cin_w)
+        if need_dx:
+            dx = ops.conv_dgrad(dt1, p.w1)
+            ops.conv_dgrad(dr, p.ws, out=dx, accumulate=True)
+    elif need_dx:
+        dx = dv
+        ops.conv_dgrad(dt1, p.w1, out=dx, accumulate=True)
+    return dx, g
+
+
+# =============================================================================== DilatedBlock
+class DilParams:
+    __slots__ = ("w", "b", "bn")
+
+    def __init__(self, ws, bs, bn):
+        self.w, self.b, self.bn = ws, bs, bn
+
+
+DIL = (1, 1, 2, 4)
+
+
+def dilated_forward(x, p: DilParams, training, save=True, stats_hook=None):
+    n, h, w, _ = x.shape
+    q = p.w[0].shape[3]
+    sm = Small(x.device)
+    cat = ops.empty_nhwc(n, h, w, 4 * q, x)
+    for i in range(4):
+        ops.conv_fwd(x, p.w[i], p.b[i], out=cat[..., i * q:(i + 1) * q], dil=DIL[i])
+    s, hsh, mean, invstd, _ = bn_coeff(cat, p.bn, training, sm, stats_hook=stats_hook)
+    out = bn_apply(cat, s, hsh, None, relu=True)
+    if not save:
+        return out, None
+    return out, dict(x=x, cat=cat, out=out, p=p, s=s, mean=mean, invstd=invstd)
+
+
+def dilated_backward(ctx, dout, need_dx=True):
+    p: DilParams = ctx["p"]
+    x, cat, out = ctx["x"], ctx["cat"], ctx["out"]
+    q = p.w[0].shape[3]
+    sm = Small(x.device)
+    g = {}
+    dcat, sums = bn_backward(dout, cat, ctx["mean"], ctx["invstd"], ctx["s"], sm, act=out, mask=None)
+    c = 4 * q
+    g["bn.bias"], g["bn.weight"] = sums[:c], sums[c:]
+    dx = None
+    for i in range(4):
+        sl = dcat[..., i * q:(i + 1) * q]
+        k = 1 if i == 0 else 3
+        g[f"conv{i + 1}.weight"] = ops.conv_wgrad(x, sl, k, k, dil=DIL[i])
+        g[f"conv{i + 1}.bias"] = chan_sum(sl, sm)
+        if need_dx:
+            dx = ops.conv_dgrad(sl, p.w[i], out=dx, dil=DIL[i], accumulate=i > 0)
+    return dx, g
+
+
+# =============================================================================== up-conv + attention gate + concat
+class UpGateParams:
+    __slots__ = ("wup", "bup", "wg", "bg", "bng", "wx", "bx", "bnx", "wpsi", "bpsi", "bnp")
+
+    def __init__(self, wup, bup, wg, bg, bng, wx, bx, bnx, wpsi, bpsi, bnp):
+        (self.wup, self.bup, self.wg, self.bg, self.bng, self.wx, self.bx, self.bnx, self.wpsi, self.bpsi, self.bnp) = (
+            wup, bup, wg, bg, bng, wx, bx, bnx, wpsi, bpsi, bnp)
+
+
+def gate_forward(up, skip, p: UpGateParams, training, att_out, sm, stats_hook=None):
+    """AttentionGate(g=up, x=skip) -> writes skip*psi into att_out; returns ctx pieces."""
+    n, h, w, c = skip.shape
+    f = p.wg.shape[3]
+    P = n * h * w
+    st = ops.stream()
+    g1 = ops.conv_fwd(up, p.wg, p.bg)
+    x1 = ops.conv_fwd(skip, p.wx, p.bx)
+    sg, hg, mean_g, invstd_g, _ = bn_coeff(g1, p.bng, training, sm, stats_hook=stats_hook)
+    sx, hx, mean_x, invstd_x, _ = bn_coeff(x1, p.bnx, training, sm, stats_hook=stats_hook)
+    s = torch.empty((n, h, w, 1), device=skip.device, dtype=torch.float32)
+    check(lib.runet_ag_psi(g1.data_ptr(), ops.ld(g1), x1.data_ptr(), ops.ld(x1), sg.data_ptr(), hg.data_ptr(), sx.data_ptr(), hx.data_ptr(),
+                           p.wpsi.data_ptr(), p.bpsi.data_ptr(), s.data_ptr(), P, f, st))
+    sp, hp, mean_p, invstd_p, _ = bn_coeff(s, p.bnp, training, sm, stats_hook=stats_hook)
+    check(lib.runet_ag_out(skip.data_ptr(), ops.ld(skip), s.data_ptr(), sp.data_ptr(), hp.data_ptr(), att_out.data_ptr(), ops.ld(att_out), P, c, st))
+    return dict(g1=g1, x1=x1, s=s, sg=sg, hg=hg, mean_g=mean_g, invstd_g=invstd_g, sx=sx, hx=hx, mean_x=mean_x, invstd_x=invstd_x,
+                sp=sp, hp=hp, mean_p=mean_p, invstd_p=invstd_p)
+
+
+def gate_backward(gc, up, skip, p: UpGateParams, datt, dup, sm, pre=""):
+    """datt: grad of the gated skip (view); dup: grad buffer of `up`, accumulated into.  -> (dskip, grads)"""
+    n, h, w, c = skip.shape
+    f = p.wg.shape[3]
+    P = n * h * w
+    st = ops.stream()
+    dev = skip.device
+    g = {}
+    dskip = ops.empty_nhwc(n, h, w, c, skip)
+    dsbn = torch.empty((n, h, w, 1), device=dev, dtype=torch.float32)
+    check(lib.runet_ag_bwd1(datt.data_ptr(), ops.ld(datt), skip.data_ptr(), ops.ld(skip), gc["s"].data_ptr(), gc["sp"].data_ptr(),
+                            gc["hp"].data_ptr(), dskip.data_ptr(), ops.ld(dskip), dsbn.data_ptr(), P, c, st))
+    ds, sums_p = bn_backward(dsbn, gc["s"], gc["mean_p"], gc["invstd_p"], gc["sp"], sm, out=dsbn)
+    g[pre + "psi.1.bias"], g[pre + "psi.1.weight"] = sums_p[:1], sums_p[1:]
+    dpre = ops.empty_nhwc(n, h, w, f, skip)
+    dwpsi_db = sm.f(f + 1)
+    ws = _ws(n, h * w, f, dev)
+    check(lib.runet_ag_bwd2(ds.data_ptr(), gc["g1"].data_ptr(), ops.ld(gc["g1"]), gc["x1"].data_ptr(), ops.ld(gc["x1"]), gc["sg"].data_ptr(),
+                            gc["hg"].data_ptr(), gc["sx"].data_ptr(), gc["hx"].data_ptr(), p.wpsi.data_ptr(), dpre.data_ptr(), ops.ld(dpre),
+                            ws.data_ptr(), dwpsi_db.data_ptr(), P, f, st))
+    g[pre + "psi.0.weight"], g[pre + "psi.0.bias"] = dwpsi_db[:f].view(1, 1, f, 1), dwpsi_db[f:]
+    dg1, sums_g = bn_backward(dpre, gc["g1"], gc["mean_g"], gc["invstd_g"], gc["sg"], sm)
+    g[pre + "W_g.1.bias"], g[pre + "W_g.1.weight"] = sums_g[:f], sums_g[f:]
+    g[pre + "W_g.0.weight"] = ops.conv_wgrad(up, dg1, 1, 1)
+    g[pre + "W_g.0.bias"] = chan_sum(dg1, sm)
+    ops.conv_dgrad(dg1, p.wg, out=dup, accumulate=True)
+    del dg1
+    dx1, sums_x = bn_backward(dpre, gc["x1"], gc["mean_x"], gc["invstd_x"], gc["sx"], sm, out=dpre)
+    g[pre + "W_x.1.bias"], g[pre + "W_x.1.weight"] = sums_x[:f], sums_x[f:]
+    g[pre + "W_x.0.weight"] = ops.conv_wgrad(skip, dx1, 1, 1)
+    g[pre + "W_x.0.bias"] = chan_sum(dx1, sm)
+    ops.conv_dgrad(dx1, p.wx, out=dskip, accumulate=True)
+    return dskip, g
+
+
+def upgate_forward(y, skip, p: UpGateParams, training, save=True, stats_hook=None):
+    """cat([AttentionGate(up, skip), up]) with up = ConvTranspose2d(y), written into one buffer."""
+    n, h, w, c = skip.shape
+    sm = Small(skip.device)
+    cat = ops.empty_nhwc(n, h, w, 2 * c, skip)
+    up = cat[..., c:]
+    ops.convt_fwd(y, p.wup, p.bup, out=up)
+    gc = gate_forward(up, skip, p, training, cat[..., :c], sm, stats_hook)
+    if not save:
+        return cat, None
+    gc.update(y=y, skip=skip, cat=cat, p=p)
+    return cat, gc
+
+
+def upgate_backward(ctx, dcat):
+    """dcat [N,H,W,2C] is consumed (its right half accumulates the gate's gradient).  -> (dy, dskip, grads)"""
+    p: UpGateParams = ctx["p"]
+    y, skip, cat = ctx["y"], ctx["skip"], ctx["cat"]
+    c = skip.shape[3]
+    sm = Small(skip.device)
+    up, dup, datt = cat[..., c:], dcat[..., c:], dcat[..., :c]
+    dskip, g = gate_backward(ctx, up, skip, p, datt, dup, sm, pre="att.")
+    g["up.weight"] = ops.convt_wgrad(y, dup)
+    g["up.bias"] = chan_sum(dup, sm)
+    dy = ops.convt_dgrad(dup, p.wup)
+    return dy, dskip, g
+
+
+# =============================================================================== pool / stem / head
+def maxpool_forward(x):
+    n, h, w, c = x.shape
+    y = ops.empty_nhwc(n, h // 2, w // 2, c, x)
+    idx = torch.empty((n, h // 2, w // 2, c), device=x.device, dtype=torch.uint8)
+    check(lib.runet_maxpool2_fwd(x.data_ptr(), ops.ld(x), y.data_ptr(), ops.ld(y), idx.data_ptr(), n, h, w, c, ops.stream()))
+    return y, idx
+
+
+def maxpool_backward(dy, idx, dx=None):
+    """dx given: accumulate into it (skip-connection gradient already there)."""
+    n, ho, wo, c = dy.shape
+    acc = dx is not None
+    if dx is None:
+        dx = ops.empty_nhwc(n, 2 * ho, 2 * wo, c, dy)
+    check(lib.runet_maxpool2_bwd(dy.data_ptr(), ops.ld(dy), idx.data_ptr(), dx.data_ptr(), ops.ld(dx), n, 2 * ho, 2 * wo, c, int(acc), ops.stream()))
+    return dx
+
+
+def to_nhwc_pad(x_nchw, c_pad):
+    n, c, h, w = x_nchw.shape
+    y = torch.empty((n, h, w, c_pad), device=x_nchw.device, dtype=torch.float32)
+    sn, sc, sh, sw = x_nchw.stride()
+    check(lib.runet_to_nhwc_pad(x_nchw.data_ptr(), sn, sc, sh, sw, y.data_ptr(), n, c, h, w, c_pad, ops.stream()))
+    return y
+
+
+def outc_forward(x, w, b, want_logit=False):
+    n, h, wd, c = x.shape
+    prob = torch.empty((n, 1, h, wd), device=x.device, dtype=torch.float32)
+    logit = torch.empty((n, 1, h, wd), device=x.device, dtype=torch.float32) if want_logit else None
+    check(lib.runet_outc_fwd(x.data_ptr(), ops.ld(x), w.data_ptr(), b.data_ptr(), logit.data_ptr() if want_logit else None, prob.data_ptr(),
+                             n * h * wd, c, ops.stream()))
+    return prob, logit
+
+
+def outc_backward(dprob, prob, x, w):
+    n, h, wd, c = x.shape
+    dx = ops.empty_nhwc(n, h, wd, c, x)
+    dw_db = torch.empty(c + 1, device=x.device, dtype=torch.float32)
+    ws = _ws(n, h * wd, c, x.device)
+    check(lib.runet_outc_bwd(dprob.data_ptr(), prob.data_ptr(), x.data_ptr(), ops.ld(x), w.data_ptr(), dx.data_ptr(), ops.ld(dx), ws.data_ptr(),
+                             dw_db.data_ptr(), n * h * wd, c, ops.stream()))
+    return dx, dw_db[:c].view(1, 1, c, 1), dw_db[c:]

@@ -473,11 +473,6 @@ extern "C" int runet_conv_igemm(const float* x, int ldx, const float* w, const f
     RUNET_CHECK_LAUNCH();
 }
 
-extern "C" long runet_conv_wgrad_workspace_floats(int n_img, int h, int w_, int cin_w, int cout, int kh, int kw) {
-    // upper bound used by the host to size the slab workspace: at most 64 splits
-    return 64L * kh * kw * cin_w * cout;
-}
-
 static int pick_splits(long P, int tiles, int ntaps) {
     const long base = (long)tiles * ntaps;
     long want = (768 + base - 1) / base;            // aim for >= 3 blocks per CU
@@ -486,6 +481,19 @@ static int pick_splits(long P, int tiles, int ntaps) {
     if (want > 64) want = 64;
     if (want < 1) want = 1;
     return (int)want;
+}
+
+static void wgrad_plan(long P, int cin_w, int cout, int ntaps, bool& big, int& tiles, int& splits) {
+    big = (cin_w > 64 && cout > 64);
+    const int BMt = big ? 128 : 64, BNt = big ? 128 : 64;
+    tiles = cdiv(cin_w, BMt) * cdiv(cout, BNt);
+    splits = pick_splits(P, tiles, ntaps);
+}
+
+extern "C" long runet_conv_wgrad_workspace_floats(int n_img, int h, int w_, int cin_w, int cout, int kh, int kw) {
+    bool big; int tiles, splits;
+    wgrad_plan((long)n_img * h * w_, cin_w, cout, kh * kw, big, tiles, splits);
+    return splits > 1 ? (long)splits * kh * kw * cin_w * cout : 0;
 }
 
 extern "C" int runet_conv_wgrad(const float* x, int ldx, const float* dy, int ldy, float* dw, float* workspace,
@@ -510,10 +518,8 @@ extern "C" int runet_conv_wgrad(const float* x, int ldx, const float* dy, int ld
     }
     const long P = (long)n_img * h * w_;
     const int ntaps = kh * kw;
-    const bool big = (cin_w > 64 && cout > 64);
-    const int BMt = big ? 128 : 64, BNt = big ? 128 : 64;
-    const int tiles = cdiv(cin_w, BMt) * cdiv(cout, BNt);
-    int splits = pick_splits(P, tiles, ntaps);
+    bool big; int tiles, splits;
+    wgrad_plan(P, cin_w, cout, ntaps, big, tiles, splits);
     const long wsize = (long)ntaps * cin_w * cout;
     if (splits > 1 && (workspace == nullptr || workspace_floats < splits * wsize)) {
         splits = workspace ? (int)(workspace_floats / wsize) : 1;

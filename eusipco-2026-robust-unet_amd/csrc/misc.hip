@@ -1,0 +1,241 @@
+// MaxPool2d(2), input layout conversion, BCE loss, fused multi-tensor Adam and segmentation counts.
+//
+// Reference call sites (/root/reference/Main_Final.py): nn.MaxPool2d(2) :235,239,243,249; nn.BCELoss() :551,580;
+// torch.optim.Adam(lr, weight_decay=1e-4) :552,582 (L2-coupled decay, bias-corrected); ModelEvaluator.calculate_metrics
+// :519-547 (thresholded tp / predicted-positive / target-positive counts; the float64 ratios stay on the host).
+// All HBM-bound: 16-byte accesses per lane, one pass.
+#include "runet_common.h"
+#include "../../include/runet_hip.h"
+
+namespace {
+constexpr int TPB = 256;
+
+inline int ew_grid(long total) {
+    long b = (total + TPB - 1) / TPB;
+    if (b > 4096) b = 4096;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+// ---- 2x2 max pool; idx byte = position (0..3) of the first maximum in scan order (ATen tie rule: strict >, NaN wins)
+__global__ __launch_bounds__(TPB) void maxpool2_fwd_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy,
+                                                           unsigned char* __restrict__ idx, int N, int Ho, int Wo, int C) {
+    const int cvec = C / 4;
+    const long total = (long)N * Ho * Wo * cvec;
+    const int W = Wo * 2;
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
+        const long op = i / cvec;
+        const int c = (int)(i - op * cvec) * 4;
+        const int wo = (int)(op % Wo);
+        const long t = op / Wo;
+        const int ho = (int)(t % Ho);
+        const long n = t / Ho;
+        const long ip = (n * (Ho * 2) + ho * 2) * W + wo * 2;
+        f32x4 m = *reinterpret_cast<const f32x4*>(x + ip * ldx + c);
+        unsigned int sel[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int k = 1; k < 4; ++k) {
+            const long q = ip + (k >> 1) * W + (k & 1);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(x + q * ldx + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (v[e] > m[e] || v[e] != v[e]) { m[e] = v[e]; sel[e] = k; }
+        }
+        *reinterpret_cast<f32x4*>(y + op * ldy + c) = m;
+        *reinterpret_cast<unsigned int*>(idx + op * C + c) = sel[0] | (sel[1] << 8) | (sel[2] << 16) | (sel[3] << 24);
+    }
+}
+__global__ __launch_bounds__(TPB) void maxpool2_bwd_kernel(const float* __restrict__ dy, int lddy, const unsigned char* __restrict__ idx,
+                                                           float* __restrict__ dx, int lddx, int N, int Ho, int Wo, int C, int accumulate) {
+    const int cvec = C / 4;
+    const long total = (long)N * Ho * Wo * cvec;
+    const int W = Wo * 2;
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
+        const long op = i / cvec;
+        const int c = (int)(i - op * cvec) * 4;
+        const int wo = (int)(op % Wo);
+        const long t = op / Wo;
+        const int ho = (int)(t % Ho);
+        const long n = t / Ho;
+        const long ip = (n * (Ho * 2) + ho * 2) * W + wo * 2;
+        const f32x4 g = *reinterpret_cast<const f32x4*>(dy + op * lddy + c);
+        const unsigned int s = *reinterpret_cast<const unsigned int*>(idx + op * C + c);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const long q = ip + (k >> 1) * W + (k & 1);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (((s >> (8 * e)) & 0xff) == (unsigned)k) ? g[e] : 0.f;
+            float* d = dx + q * lddx + c;
+            if (accumulate) o += *reinterpret_cast<const f32x4*>(d);
+            *reinterpret_cast<f32x4*>(d) = o;
+        }
+    }
+}
+
+// ---- strided [N,C,H,W] (any strides) -> NHWC with channels zero-padded to Cp
+__global__ __launch_bounds__(TPB) void to_nhwc_pad_kernel(const float* __restrict__ x, long sn, long sc, long sh, long sw,
+                                                          float* __restrict__ y, int N, int C, int H, int W, int Cp) {
+    const long total = (long)N * H * W;
+    for (long p = (long)blockIdx.x * TPB + threadIdx.x; p < total; p += (long)gridDim.x * TPB) {
+        const int w = (int)(p % W);
+        const long t = p / W;
+        const int h = (int)(t % H);
+        const long n = t / H;
+        const float* src = x + n * sn + h * sh + w * sw;
+        for (int c = 0; c < Cp; ++c) y[p * Cp + c] = c < C ? src[c * sc] : 0.f;
+    }
+}
+
+// ---- BCE (mean) on probabilities, ATen semantics: logs clamped at -100
+__global__ __launch_bounds__(TPB) void bce_partial_kernel(const float* __restrict__ p, const float* __restrict__ y, long n,
+                                                          double* __restrict__ part) {
+    double acc = 0;
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long)gridDim.x * TPB) {
+        const float pi = p[i], yi = y[i];
+        const float lp = fmaxf(logf(pi), -100.f), l1 = fmaxf(logf(1.f - pi), -100.f);
+        acc -= (double)(yi * lp + (1.f - yi) * l1);
+    }
+    acc = wave_sum_d(acc);
+    __shared__ double red[TPB / 64];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void bce_final_kernel(const double* __restrict__ part, int nparts, long n, float* __restrict__ loss) {
+    double acc = 0;
+    for (int i = threadIdx.x; i < nparts; i += 64) acc += part[i];
+    acc = wave_sum_d(acc);
+    if (threadIdx.x == 0) loss[0] = (float)(acc / (double)n);
+}
+__global__ __launch_bounds__(TPB) void bce_bwd_kernel(const float* __restrict__ p, const float* __restrict__ y,
+                                                      const float* __restrict__ gout, float* __restrict__ dp, long n) {
+    const float g = (gout ? gout[0] : 1.f) / (float)n;
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long)gridDim.x * TPB) {
+        const float pi = p[i];
+        dp[i] = g * (pi - y[i]) / fmaxf(pi * (1.f - pi), 1e-12f);
+    }
+}
+
+// ---- multi-tensor Adam.  table: int64 [5][T] = p, g, m, v pointers and element counts; chunks: int32 [B][2] = (tensor, chunk#)
+constexpr int ADAM_CHUNK = 16384;
+__global__ __launch_bounds__(TPB) void adam_multi_kernel(const long long* __restrict__ table, int T, const int* __restrict__ chunks,
+                                                         float lr, float beta1, float beta2, float eps, float wd, float bc1,
+                                                         float bc2_sqrt, float grad_scale) {
+    const int t = chunks[blockIdx.x * 2], ck = chunks[blockIdx.x * 2 + 1];
+    float* p = reinterpret_cast<float*>(table[t]);
+    const float* g = reinterpret_cast<const float*>(table[T + t]);
+    float* m = reinterpret_cast<float*>(table[2 * T + t]);
+    float* v = reinterpret_cast<float*>(table[3 * T + t]);
+    const long n = table[4 * T + t];
+    const long beg = (long)ck * ADAM_CHUNK;
+    const long end = beg + ADAM_CHUNK < n ? beg + ADAM_CHUNK : n;
+    const float step = lr / bc1;
+    auto upd = [&](float& pv, float gv, float& mv, float& vv) {
+        gv = gv * grad_scale + wd * pv;
+        mv = beta1 * mv + (1.f - beta1) * gv;
+        vv = beta2 * vv + (1.f - beta2) * gv * gv;
+        pv -= step * mv / (sqrtf(vv) / bc2_sqrt + eps);
+    };
+    const bool al = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0);
+    if (al) {
+        const long nv = (end - beg) / 4;
+        for (long i = threadIdx.x; i < nv; i += TPB) {
+            const long o = beg + i * 4;
+            f32x4 pv = *reinterpret_cast<f32x4*>(p + o), mv = *reinterpret_cast<f32x4*>(m + o), vv = *reinterpret_cast<f32x4*>(v + o);
+            const f32x4 gv = *reinterpret_cast<const f32x4*>(g + o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { float a = pv[e], b = mv[e], c = vv[e]; upd(a, gv[e], b, c); pv[e] = a; mv[e] = b; vv[e] = c; }
+            *reinterpret_cast<f32x4*>(p + o) = pv; *reinterpret_cast<f32x4*>(m + o) = mv; *reinterpret_cast<f32x4*>(v + o) = vv;
+        }
+        for (long o = beg + nv * 4 + threadIdx.x; o < end; o += TPB) upd(p[o], g[o], m[o], v[o]);
+    } else {
+        for (long o = beg + threadIdx.x; o < end; o += TPB) upd(p[o], g[o], m[o], v[o]);
+    }
+}
+
+// ---- per-image counts: [n][0]=tp, [1]=predicted positives, [2]=target positives, [3]=pixels where (pred>thr) == (target!=0)
+__global__ __launch_bounds__(TPB) void seg_counts_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                         long long* __restrict__ counts, long per_img, float thr) {
+    const int n = blockIdx.y;
+    const float* p = pred + (long)n * per_img;
+    const float* t = target + (long)n * per_img;
+    long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < per_img; i += (long)gridDim.x * TPB) {
+        const bool pb = p[i] > thr, tb = t[i] != 0.f;
+        c0 += pb && tb; c1 += pb; c2 += tb; c3 += pb == tb;
+    }
+    auto wred = [](long long v) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        return v;
+    };
+    c0 = wred(c0); c1 = wred(c1); c2 = wred(c2); c3 = wred(c3);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(reinterpret_cast<unsigned long long*>(counts + n * 4 + 0), (unsigned long long)c0);
+        atomicAdd(reinterpret_cast<unsigned long long*>(counts + n * 4 + 1), (unsigned long long)c1);
+        atomicAdd(reinterpret_cast<unsigned long long*>(counts + n * 4 + 2), (unsigned long long)c2);
+        atomicAdd(reinterpret_cast<unsigned long long*>(counts + n * 4 + 3), (unsigned long long)c3);
+    }
+}
+}  // namespace
+
+extern "C" int runet_maxpool2_fwd(const float* x, int ldx, float* y, int ldy, unsigned char* idx, int n_img, int h, int w, int c, void* stream) {
+    RUNET_REQUIRE(x && y && idx, "null pointer");
+    RUNET_REQUIRE(h % 2 == 0 && w % 2 == 0 && c % 4 == 0 && c > 0, "h, w must be even and c a multiple of 4");
+    const long total = (long)n_img * (h / 2) * (w / 2) * (c / 4);
+    hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(ew_grid(total)), dim3(TPB), 0, (hipStream_t)stream, x, ldx, y, ldy, idx, n_img, h / 2, w / 2, c);
+    RUNET_CHECK_LAUNCH();
+}
+
+extern "C" int runet_maxpool2_bwd(const float* dy, int lddy, const unsigned char* idx, float* dx, int lddx, int n_img, int h, int w, int c,
+                                  int accumulate, void* stream) {
+    RUNET_REQUIRE(dy && dx && idx, "null pointer");
+    RUNET_REQUIRE(h % 2 == 0 && w % 2 == 0 && c % 4 == 0 && c > 0, "h, w must be even and c a multiple of 4");
+    const long total = (long)n_img * (h / 2) * (w / 2) * (c / 4);
+    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(ew_grid(total)), dim3(TPB), 0, (hipStream_t)stream, dy, lddy, idx, dx, lddx, n_img, h / 2, w / 2, c, accumulate);
+    RUNET_CHECK_LAUNCH();
+}
+
+extern "C" int runet_to_nhwc_pad(const float* x, long sn, long sc, long sh, long sw, float* y, int n_img, int c, int h, int w, int c_pad, void* stream) {
+    RUNET_REQUIRE(x && y && c > 0 && c_pad >= c, "bad arguments");
+    hipLaunchKernelGGL(to_nhwc_pad_kernel, dim3(ew_grid((long)n_img * h * w)), dim3(TPB), 0, (hipStream_t)stream, x, sn, sc, sh, sw, y, n_img, c, h, w, c_pad);
+    RUNET_CHECK_LAUNCH();
+}
+
+extern "C" int runet_bce_fwd(const float* prob, const float* target, long n, double* workspace1024, float* loss, void* stream) {
+    RUNET_REQUIRE(prob && target && workspace1024 && loss && n > 0, "bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    long b = (n + TPB * 8 - 1) / (TPB * 8);
+    if (b > 1024) b = 1024;
+    hipLaunchKernelGGL(bce_partial_kernel, dim3((int)b), dim3(TPB), 0, st, prob, target, n, workspace1024);
+    hipLaunchKernelGGL(bce_final_kernel, dim3(1), dim3(64), 0, st, workspace1024, (int)b, n, loss);
+    RUNET_CHECK_LAUNCH();
+}
+
+extern "C" int runet_bce_bwd(const float* prob, const float* target, const float* grad_out, float* dprob, long n, void* stream) {
+    RUNET_REQUIRE(prob && target && dprob && n > 0, "bad arguments");
+    hipLaunchKernelGGL(bce_bwd_kernel, dim3(ew_grid(n)), dim3(TPB), 0, (hipStream_t)stream, prob, target, grad_out, dprob, n);
+    RUNET_CHECK_LAUNCH();
+}
+
+extern "C" int runet_adam_chunk_elems(void) { return ADAM_CHUNK; }
+
+extern "C" int runet_adam_multi(const long long* table, int n_tensors, const int* chunks, int n_chunks, float lr, float beta1, float beta2,
+                                float eps, float weight_decay, int step, float grad_scale, void* stream) {
+    RUNET_REQUIRE(table && chunks && n_tensors > 0 && n_chunks > 0 && step >= 1, "bad arguments");
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    hipLaunchKernelGGL(adam_multi_kernel, dim3(n_chunks), dim3(TPB), 0, (hipStream_t)stream, table, n_tensors, chunks, lr, beta1, beta2, eps,
+                       weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale);
+    RUNET_CHECK_LAUNCH();
+}
+
+extern "C" int runet_seg_counts(const float* pred, const float* target, long long* counts, int n_img, long per_img, float threshold, void* stream) {
+    RUNET_REQUIRE(pred && target && counts && n_img > 0 && per_img > 0, "bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(counts, 0, sizeof(long long) * 4 * n_img, st) != hipSuccess) { runet_set_error("runet_seg_counts: memset failed"); return RUNET_ELAUNCH; }
+    long b = (per_img + TPB * 4 - 1) / (TPB * 4);
+    if (b > 256) b = 256;
+    hipLaunchKernelGGL(seg_counts_kernel, dim3((int)b, n_img), dim3(TPB), 0, st, pred, target, counts, per_img, threshold);
+    RUNET_CHECK_LAUNCH();
+}

@@ -368,7 +368,12 @@ inline int ew_grid(long total_vec) {
 #define REQ_VEC(C) RUNET_REQUIRE((C) >= 1 && (C) <= 1024 && ((C) % 4 == 0 || (C) == 1), "channels must be 1 or a multiple of 4, at most 1024")
 
 extern "C" long runet_reduce_workspace_floats(int n_img, int hw, int c) {
-    return (long)n_img * 1024L * c * 7 + 64;
+    // covers every partial-reduction kernel of this library for an [n_img, hw, c] tensor
+    const int vec = (c % 4 == 0) ? 4 : 1;
+    const int rows = TPB / (c / vec > 0 ? c / vec : 1);
+    const long a = (long)n_img * pick_chunks(n_img, hw, c, rows > 0 ? rows : 1) * c * 7;
+    const long b = 2048L * (c + 1);
+    return (a > b ? a : b) + 64;
 }
 
 extern "C" int runet_chan_stats(const float* x, int ld, int n_img, int hw, int c, float* workspace, float* mean_nc,

@@ -120,3 +120,44 @@ def convt_wgrad(x, dy, out=None):
     check(lib.runet_conv_wgrad(x.data_ptr(), ld(x), dy.data_ptr(), ld(dy), out.data_ptr(), ws.data_ptr(), ws.numel(),
                                n, h, w, cin, cin, cout, 2, 2, 1, 1, stream()))
     return out
+
+
+# ------------------------------------------------------------------------------- loss / metrics
+class _BCELoss(torch.autograd.Function):
+    """nn.BCELoss() (mean) on probabilities, ATen semantics (/root/reference/Main_Final.py:551,580)."""
+
+    @staticmethod
+    def forward(ctx, prob, target):
+        prob, target = prob.contiguous(), target.contiguous()
+        n = prob.numel()
+        loss = torch.empty((), device=prob.device, dtype=torch.float32)
+        part = torch.empty(1024, device=prob.device, dtype=torch.float64)
+        check(lib.runet_bce_fwd(prob.data_ptr(), target.data_ptr(), n, part.data_ptr(), loss.data_ptr(), stream()))
+        ctx.save_for_backward(prob, target)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        prob, target = ctx.saved_tensors
+        dprob = torch.empty_like(prob)
+        gout = gout.contiguous()
+        check(lib.runet_bce_bwd(prob.data_ptr(), target.data_ptr(), gout.data_ptr(), dprob.data_ptr(), prob.numel(), stream()))
+        return dprob, None
+
+
+def bce_loss(prob, target):
+    if not prob.is_cuda:
+        raise RuntimeError("bce_loss runs on the HIP device only")
+    if prob.shape != target.shape:
+        raise ValueError(f"shape mismatch {tuple(prob.shape)} vs {tuple(target.shape)}")
+    return _BCELoss.apply(prob, target.to(torch.float32))
+
+
+def seg_counts(pred, target, threshold=0.5):
+    """pred, target: [N, ...] -> int64 [N, 4] = (tp, predicted positives, target positives, agreeing pixels)."""
+    pred, target = pred.contiguous(), target.contiguous().to(torch.float32)
+    n = pred.shape[0]
+    per = pred.numel() // n
+    counts = torch.empty((n, 4), device=pred.device, dtype=torch.int64)
+    check(lib.runet_seg_counts(pred.data_ptr(), target.data_ptr(), counts.data_ptr(), n, per, float(threshold), stream()))
+    return counts

@@ -1,0 +1,75 @@
+"""Fused multi-tensor Adam with the semantics of `torch.optim.Adam(params, lr, weight_decay)` as the
+reference uses it (/root/reference/Main_Final.py:552,582): L2-coupled weight decay (grad += wd * p),
+bias-corrected, eps added after the sqrt.  All parameter tensors are updated by ONE kernel launch
+(runet_adam_multi): a device table of (param, grad, exp_avg, exp_avg_sq, numel) rows plus a chunk list.
+
+It is a torch.optim.Optimizer (param_groups / zero_grad / state_dict / lr schedulers such as
+ReduceLROnPlateau work unchanged).  Parameters may have any dense memory layout (model.py stores conv
+weights HWIO): the update is elementwise over the underlying storage, and the gradient must be laid
+out like its parameter (RobustUNet's backward produces exactly that).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from ._lib import check, lib
+
+
+def _dense_like(p, g):
+    return g.shape == p.shape and g.stride() == p.stride()
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._tables = {}
+        self.grad_scale = 1.0     # multiplied into the gradient (1/world_size after a SUM all-reduce)
+
+    def _table(self, gi, plist):
+        key_ptrs = tuple(t.data_ptr() for p in plist for t in (p, p.grad, self.state[p]["exp_avg"], self.state[p]["exp_avg_sq"]))
+        cached = self._tables.get(gi)
+        if cached is not None and cached[0] == key_ptrs:
+            return cached[1], cached[2], cached[3]
+        T = len(plist)
+        tab = np.zeros((5, T), dtype=np.int64)
+        chunk = lib.runet_adam_chunk_elems()
+        chunks = []
+        for i, p in enumerate(plist):
+            st = self.state[p]
+            tab[:, i] = (p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel())
+            chunks += [(i, c) for c in range((p.numel() + chunk - 1) // chunk)]
+        dev = plist[0].device
+        d_tab = torch.from_numpy(tab).to(dev)
+        d_chunks = torch.tensor(chunks, dtype=torch.int32).to(dev)
+        self._tables[gi] = (key_ptrs, d_tab, d_chunks, len(chunks))
+        return d_tab, d_chunks, len(chunks)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for gi, group in enumerate(self.param_groups):
+            plist = [p for p in group["params"] if p.grad is not None]
+            if not plist:
+                continue
+            for p in plist:
+                if not p.is_cuda:
+                    raise RuntimeError("FusedAdam updates HIP-device parameters only")
+                if not _dense_like(p, p.grad):
+                    p.grad = torch.empty_like(p, memory_format=torch.preserve_format).copy_(p.grad)
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] += 1
+            step = self.state[plist[0]]["step"]
+            d_tab, d_chunks, n_chunks = self._table(gi, plist)
+            b1, b2 = group["betas"]
+            check(lib.runet_adam_multi(d_tab.data_ptr(), len(plist), d_chunks.data_ptr(), n_chunks, float(group["lr"]), float(b1), float(b2),
+                                       float(group["eps"]), float(group["weight_decay"]), int(step), float(self.grad_scale),
+                                       torch.cuda.current_stream().cuda_stream))
+        return loss

@@ -49,6 +49,103 @@ int runet_conv_wgrad(const float* x, int ldx, const float* dy, int ldy, float* d
                      long workspace_floats, int n_img, int h, int w_, int cin, int cin_w, int cout,
                      int kh, int kw, int dil, int transposed, void* stream);
 
+
+/* ---- channel statistics / BatchNorm2d / ReLU / Dropout2d (Main_Final.py:158,160,162,163,173,127,132,137,210,211) ----
+ * Scratch buffers ("workspace") are caller-owned; runet_reduce_workspace_floats gives a sufficient size. */
+long runet_reduce_workspace_floats(int n_img, int hw, int c);
+
+/* per-(image, channel) mean and M2 (= sum of squared deviations) of x[n, hw, 0:c]; optionally max/min and the
+ * pixel index (within the image) of their first occurrence.  c is 1 or a multiple of 4, <= 1024. */
+int runet_chan_stats(const float* x, int ld, int n_img, int hw, int c, float* workspace, float* mean_nc, float* m2_nc,
+                     float* max_nc, float* min_nc, int* imax_nc, int* imin_nc, int want_minmax, void* stream);
+
+/* training != 0: batch statistics over n_img*hw values from (mean_nc, m2_nc); updates run_mean/run_var (momentum,
+ * unbiased variance) and *num_batches_tracked += 1 when those pointers are non-NULL; writes save_mean/save_invstd.
+ * training == 0: statistics = run_mean/run_var.  Outputs scale = gamma*invstd, shift = beta - mean*scale. */
+int runet_bn_finalize(const float* mean_nc, const float* m2_nc, int n_img, int c, long hw, const float* gamma, const float* beta,
+                      float* run_mean, float* run_var, long long* num_batches_tracked, float momentum, float eps, int training,
+                      float* scale, float* shift, float* save_mean, float* save_invstd, void* stream);
+
+/* y = [relu](x*scale[c] + shift[c]) [* mask_nc[n, c]]   (mask = Dropout2d keep-mask already divided by 1-p, or NULL) */
+int runet_bn_apply(const float* x, int ldx, float* y, int ldy, long pixels, int hw, int c, const float* scale, const float* shift,
+                   const float* mask_nc, int relu, void* stream);
+
+/* g = dy, or dy*mask_nc[n,c]*(act > 0) when act != NULL (act = saved output of relu/dropout).
+ * sums[0:c] = sum g (= dbeta), sums[c:2c] = sum g*xhat (= dgamma). */
+int runet_bn_bwd_reduce(const float* dy, int lddy, const float* x, int ldx, const float* act, int ldact, int n_img, int hw, int c,
+                        const float* mean, const float* invstd, const float* mask_nc, float* workspace, float* sums, void* stream);
+/* dx = scale*(g - sums[c]/M - xhat*sums[C+c]/M), M = pixels */
+int runet_bn_bwd_apply(const float* dy, int lddy, const float* x, int ldx, const float* act, int ldact, float* dx, int lddx,
+                       long pixels, int hw, int c, const float* mean, const float* invstd, const float* scale, const float* sums,
+                       const float* mask_nc, void* stream);
+/* out[c] (=|+=) sum over pixels of x[p, c]  (bias gradients) */
+int runet_chan_sum(const float* x, int ld, long pixels, int c, float* workspace, float* out, int accumulate, void* stream);
+
+/* ---- ChannelAttention / SpatialAttention / ResidualBlock tail (Main_Final.py:82-117, 186-194) ----
+ * w0p = ca.fc.0 weight as [C][Cr], w2p = ca.fc.2 weight as [Cr][C], wp = sa.conv1 weight as [7][7][2]. */
+int runet_ca_coeff(const float* mean_nc, const float* max_nc, const float* min_nc, const int* imax_nc, const int* imin_nc,
+                   const float* s2, const float* h2, const float* w0p, const float* w2p, int n_img, int c, int cr, float* A, float* B,
+                   float* ca, float* avg, float* mx, int* idx, float* tval, void* stream);
+int runet_sa_reduce(const float* t2, int ld, const float* A, const float* B, long pixels, int hw, int c, float* smap, int* amax,
+                    void* stream);
+int runet_sa_conv7(const float* smap, const float* wp, float* sa, int n_img, int h, int w, void* stream);
+/* out = relu((t2*A[n,c]+B[n,c])*sa[p] + res),  res = r*rs[c]+rh[c]  (rs == NULL: res = r, identity shortcut) */
+int runet_rb_out(const float* t2, int ld, const float* A, const float* B, const float* sa, const float* r, int ldr, const float* rs,
+                 const float* rh, float* out, int ldo, long pixels, int hw, int c, void* stream);
+int runet_rb_bwd1(const float* dout, int lddo, const float* out, int ldo, const float* t2, int ld, const float* A, const float* B,
+                  const float* sa, float* dv, int lddv, float* dq, long pixels, int hw, int c, void* stream);
+long runet_sa_conv7_bwd_workspace_floats(int n_img, int h, int w);
+int runet_sa_conv7_bwd(const float* smap, const float* dq, const float* wp, float* dsm, float* dwp, float* workspace, int n_img, int h,
+                       int w, void* stream);
+int runet_rb_bwd2(const float* dv, int lddv, const float* t2, int ld, const float* sa, const float* dsm, const int* amax, int n_img,
+                  int hw, int c, float* workspace, float* sdu, float* sdut, void* stream);
+long runet_ca_bwd_workspace_floats(int n_img, int c, int cr);
+int runet_ca_bwd(const float* sdu, const float* sdut, const float* s2, const float* h2, const float* ca, const float* avg, const float* mx,
+                 const float* w0p, const float* w2p, const float* mean_nc, const float* tval, const float* mean2, const float* invstd2,
+                 int n_img, int c, int cr, float* workspace, float* davg, float* dmx, float* sums2, float* dw0p, float* dw2p, void* stream);
+int runet_rb_bwd3(const float* dv, int lddv, const float* t2, int ld, const float* sa, const float* dsm, const int* amax, const float* ca,
+                  const float* davg, const float* dmx, const int* idx, const float* mean2, const float* invstd2, const float* s2,
+                  const float* sums2, float* dt2, int lddt, long pixels, int hw, int c, void* stream);
+
+/* ---- AttentionGate (Main_Final.py:120-148): psi conv (F_int -> 1) and the gating multiply ---- */
+int runet_ag_psi(const float* g1, int ldg, const float* x1, int ldx, const float* sg, const float* hg, const float* sx, const float* hx,
+                 const float* wpsi, const float* bpsi, float* s, long pixels, int f, void* stream);
+int runet_ag_out(const float* xs, int ldx, const float* s, const float* sp, const float* hp, float* out, int ldo, long pixels, int c,
+                 void* stream);
+int runet_ag_bwd1(const float* datt, int ldd, const float* xs, int ldx, const float* s, const float* sp, const float* hp, float* dxs,
+                  int lddx, float* dsbn, long pixels, int c, void* stream);
+/* dwpsi_db: [f] weight gradient followed by the bias gradient at index f */
+int runet_ag_bwd2(const float* ds, const float* g1, int ldg, const float* x1, int ldx, const float* sg, const float* hg, const float* sx,
+                  const float* hx, const float* wpsi, float* dpre, int ldp, float* workspace, float* dwpsi_db, long pixels, int f,
+                  void* stream);
+
+/* ---- outc: Conv2d(C, 1, 1) + Sigmoid (Main_Final.py:274-277) ---- */
+int runet_outc_fwd(const float* x, int ld, const float* w, const float* b, float* logit, float* prob, long pixels, int c, void* stream);
+int runet_outc_bwd(const float* dprob, const float* prob, const float* x, int ld, const float* w, float* dx, int lddx, float* workspace,
+                   float* dw_db, long pixels, int c, void* stream);
+
+/* ---- MaxPool2d(2) (Main_Final.py:235,239,243,249); idx: one byte per output element ---- */
+int runet_maxpool2_fwd(const float* x, int ldx, float* y, int ldy, unsigned char* idx, int n_img, int h, int w, int c, void* stream);
+int runet_maxpool2_bwd(const float* dy, int lddy, const unsigned char* idx, float* dx, int lddx, int n_img, int h, int w, int c,
+                       int accumulate, void* stream);
+/* strided [N,C,H,W] -> dense NHWC with channels zero-padded to c_pad (module entry: Main_Final.py:290 input x) */
+int runet_to_nhwc_pad(const float* x, long sn, long sc, long sh, long sw, float* y, int n_img, int c, int h, int w, int c_pad, void* stream);
+
+/* ---- nn.BCELoss() mean (Main_Final.py:551,580): logs clamped at -100; backward (p-y)/max(p(1-p),1e-12)/n * grad_out[0] ---- */
+int runet_bce_fwd(const float* prob, const float* target, long n, double* workspace1024, float* loss, void* stream);
+int runet_bce_bwd(const float* prob, const float* target, const float* grad_out, float* dprob, long n, void* stream);
+
+/* ---- torch.optim.Adam(lr, weight_decay) (Main_Final.py:552,582), all tensors in one launch ----
+ * table: device int64 [5][n_tensors] = param, grad, exp_avg, exp_avg_sq pointers, element counts;
+ * chunks: device int32 [n_chunks][2] = (tensor index, chunk index), chunk = runet_adam_chunk_elems() elements.
+ * grad_scale multiplies the gradient first (1/world_size after a sum all-reduce). */
+int runet_adam_chunk_elems(void);
+int runet_adam_multi(const long long* table, int n_tensors, const int* chunks, int n_chunks, float lr, float beta1, float beta2, float eps,
+                     float weight_decay, int step, float grad_scale, void* stream);
+
+/* ---- ModelEvaluator.calculate_metrics counts (Main_Final.py:519-547): counts[n] = {tp, pred>thr, target!=0, agree} ---- */
+int runet_seg_counts(const float* pred, const float* target, long long* counts, int n_img, long per_img, float threshold, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
