@@ -11,6 +11,8 @@ import ctypes as C
 import os
 import re
 
+import torch  # noqa: F401  (first: librunet_hip.so must bind to the HIP runtime that torch already loaded, not a second copy)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "librunet_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "runet_hip.h")

@@ -63,6 +63,32 @@ def _ws(n, hw, c, device):
     return scratch(lib.runet_reduce_workspace_floats(n, hw, c), device)
 
 
+class DictSink:
+    """Default gradient sink: fresh device tensors, collected in a dict keyed by parameter name."""
+
+    def __init__(self, device):
+        self.device = device
+        self.g = {}
+
+    def buf(self, prefix, items):
+        """items: [(param name, physical shape)] laid out back to back -> flat float32 view over all of them."""
+        total = sum(_numel(sh) for _, sh in items)
+        flat = torch.empty(total, device=self.device, dtype=torch.float32)
+        off = 0
+        for name, sh in items:
+            n = _numel(sh)
+            self.g[prefix + name] = flat[off:off + n].view(sh)
+            off += n
+        return flat
+
+
+def _numel(shape):
+    n = 1
+    for d in shape:
+        n *= d
+    return n
+
+
 class BNState:
     """Physical handles of one BatchNorm2d (parameters + buffers)."""
     __slots__ = ("weight", "bias", "running_mean", "running_var", "nbt")
@@ -111,12 +137,11 @@ def bn_apply(x, scale, shift, mask=None, relu=False, out=None):
     return out
 
 
-def bn_backward(dy, x, mean, invstd, scale, sm: Small, act=None, mask=None, out=None, m_total=None):
-    """-> (dx, sums) with sums[:c] = dbeta, sums[c:] = dgamma.  act/mask: fused relu(+dropout) backward."""
+def bn_backward(dy, x, mean, invstd, scale, sums, act=None, mask=None, out=None):
+    """sums: [2c] destination for (dgamma | dbeta).  act/mask: fused relu(+dropout) backward.  -> dx"""
     n, h, w, c = x.shape
     hw = h * w
     st = ops.stream()
-    sums = sm.f(2 * c)
     ws = _ws(n, hw, c, x.device)
     actp, lda = (act.data_ptr(), ops.ld(act)) if act is not None else (None, 0)
     maskp = mask.data_ptr() if mask is not None else None
@@ -126,12 +151,11 @@ def bn_backward(dy, x, mean, invstd, scale, sm: Small, act=None, mask=None, out=
         out = ops.empty_nhwc(n, h, w, c, x)
     check(lib.runet_bn_bwd_apply(dy.data_ptr(), ops.ld(dy), x.data_ptr(), ops.ld(x), actp, lda, out.data_ptr(), ops.ld(out), n * hw, hw, c,
                                  mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), sums.data_ptr(), maskp, st))
-    return out, sums
+    return out
 
 
-def chan_sum(x, sm: Small):
+def chan_sum(x, out):
     n, h, w, c = x.shape
-    out = sm.f(c)
     ws = _ws(n, h * w, c, x.device)
     check(lib.runet_chan_sum(x.data_ptr(), ops.ld(x), n * h * w, c, ws.data_ptr(), out.data_ptr(), 0, ops.stream()))
     return out
@@ -190,8 +214,8 @@ def rb_forward(x, p: RBParams, training, mask=None, save=True, stats_hook=None):
     return out, ctx
 
 
-def rb_backward(ctx, dout, need_dx=True):
-    """-> (dx or None, grads dict keyed like the module's parameters, physical layouts)."""
+def rb_backward(ctx, dout, sink, pre="", need_dx=True):
+    """Parameter gradients go to `sink` (names prefixed with `pre`).  -> dx or None"""
     p: RBParams = ctx["p"]
     x, r, t1, a1, t2, out = ctx["x"], ctx["r"], ctx["t1"], ctx["a1"], ctx["t2"], ctx["out"]
     n, h, w, c = out.shape
@@ -201,52 +225,49 @@ def rb_backward(ctx, dout, need_dx=True):
     dev = x.device
     sm = Small(dev)
     A, B, sa, smap, amax = ctx["A"], ctx["B"], ctx["sa"], ctx["smap"], ctx["amax"]
-    g = {}
     dv = ops.empty_nhwc(n, h, w, c, x)
     dq = torch.empty(P, device=dev, dtype=torch.float32)
     check(lib.runet_rb_bwd1(dout.data_ptr(), ops.ld(dout), out.data_ptr(), ops.ld(out), t2.data_ptr(), ops.ld(t2), A.data_ptr(), B.data_ptr(),
                             sa.data_ptr(), dv.data_ptr(), ops.ld(dv), dq.data_ptr(), P, hw, c, st))
     dsm = torch.empty((P, 2), device=dev, dtype=torch.float32)
-    dwsa = torch.empty((7, 7, 2, 1), device=dev, dtype=torch.float32)
+    dwsa = sink.buf(pre, [("sa.conv1.weight", (7, 7, 2, 1))])
     ws = scratch(lib.runet_sa_conv7_bwd_workspace_floats(n, h, w), dev)
     check(lib.runet_sa_conv7_bwd(smap.data_ptr(), dq.data_ptr(), p.wsa.data_ptr(), dsm.data_ptr(), dwsa.data_ptr(), ws.data_ptr(), n, h, w, st))
-    g["sa.conv1.weight"] = dwsa
     sdu, sdut = sm.f(n * c), sm.f(n * c)
     ws = _ws(n, hw, c, dev)
     check(lib.runet_rb_bwd2(dv.data_ptr(), ops.ld(dv), t2.data_ptr(), ops.ld(t2), sa.data_ptr(), dsm.data_ptr(), amax.data_ptr(), n, hw, c,
                             ws.data_ptr(), sdu.data_ptr(), sdut.data_ptr(), st))
-    davg, dmx, sums2 = sm.f(n * c), sm.f(n * c), sm.f(2 * c)
-    dw0p = torch.empty((1, 1, c, cr), device=dev, dtype=torch.float32)
-    dw2p = torch.empty((1, 1, cr, c), device=dev, dtype=torch.float32)
+    davg, dmx = sm.f(n * c), sm.f(n * c)
+    sums2 = sink.buf(pre, [("bn2.weight", (c,)), ("bn2.bias", (c,))])
+    dw0p = sink.buf(pre, [("ca.fc.0.weight", (1, 1, c, cr))])
+    dw2p = sink.buf(pre, [("ca.fc.2.weight", (1, 1, cr, c))])
     ws = scratch(lib.runet_ca_bwd_workspace_floats(n, c, cr), dev)
     check(lib.runet_ca_bwd(sdu.data_ptr(), sdut.data_ptr(), ctx["s2"].data_ptr(), ctx["h2"].data_ptr(), ctx["ca"].data_ptr(),
                            ctx["avg"].data_ptr(), ctx["mx"].data_ptr(), p.w0p.data_ptr(), p.w2p.data_ptr(), ctx["mean_nc"].data_ptr(),
                            ctx["tval"].data_ptr(), ctx["mean2"].data_ptr(), ctx["invstd2"].data_ptr(), n, c, cr, ws.data_ptr(),
                            davg.data_ptr(), dmx.data_ptr(), sums2.data_ptr(), dw0p.data_ptr(), dw2p.data_ptr(), st))
-    g["ca.fc.0.weight"], g["ca.fc.2.weight"] = dw0p, dw2p
-    g["bn2.bias"], g["bn2.weight"] = sums2[:c], sums2[c:]
     dt2 = ops.empty_nhwc(n, h, w, c, x)
     check(lib.runet_rb_bwd3(dv.data_ptr(), ops.ld(dv), t2.data_ptr(), ops.ld(t2), sa.data_ptr(), dsm.data_ptr(), amax.data_ptr(),
                             ctx["ca"].data_ptr(), davg.data_ptr(), dmx.data_ptr(), ctx["idx"].data_ptr(), ctx["mean2"].data_ptr(),
                             ctx["invstd2"].data_ptr(), ctx["s2"].data_ptr(), sums2.data_ptr(), dt2.data_ptr(), ops.ld(dt2), P, hw, c, st))
-    g["conv2.weight"] = ops.conv_wgrad(a1, dt2, 3, 3)
+    ops.conv_wgrad(a1, dt2, 3, 3, out=sink.buf(pre, [("conv2.weight", (3, 3, c, c))]))
     da1 = ops.conv_dgrad(dt2, p.w2)
     del dt2
-    dt1, sums1 = bn_backward(da1, t1, ctx["mean1"], ctx["invstd1"], ctx["s1"], sm, act=a1, mask=ctx["mask"], out=da1)
-    g["bn1.bias"], g["bn1.weight"] = sums1[:c], sums1[c:]
-    g["conv1.weight"] = ops.conv_wgrad(x, dt1, 3, 3, cin_w=p.cin_w)
+    sums1 = sink.buf(pre, [("bn1.weight", (c,)), ("bn1.bias", (c,))])
+    dt1 = bn_backward(da1, t1, ctx["mean1"], ctx["invstd1"], ctx["s1"], sums1, act=a1, mask=ctx["mask"], out=da1)
+    ops.conv_wgrad(x, dt1, 3, 3, cin_w=p.cin_w, out=sink.buf(pre, [("conv1.weight", (3, 3, p.cin_w, c))]))
     dx = None
     if p.ws is not None:
-        dr, sums_s = bn_backward(dv, r, ctx["mean_s"], ctx["invstd_s"], ctx["ss"], sm, out=dv)
-        g["shortcut.1.bias"], g["shortcut.1.weight"] = sums_s[:c], sums_s[c:]
-        g["shortcut.0.weight"] = ops.conv_wgrad(x, dr, 1, 1, cin_w=p.cin_w)
+        sums_s = sink.buf(pre, [("shortcut.1.weight", (c,)), ("shortcut.1.bias", (c,))])
+        dr = bn_backward(dv, r, ctx["mean_s"], ctx["invstd_s"], ctx["ss"], sums_s, out=dv)
+        ops.conv_wgrad(x, dr, 1, 1, cin_w=p.cin_w, out=sink.buf(pre, [("shortcut.0.weight", (1, 1, p.cin_w, c))]))
         if need_dx:
             dx = ops.conv_dgrad(dt1, p.w1)
             ops.conv_dgrad(dr, p.ws, out=dx, accumulate=True)
     elif need_dx:
         dx = dv
         ops.conv_dgrad(dt1, p.w1, out=dx, accumulate=True)
-    return dx, g
+    return dx
 
 
 # =============================================================================== DilatedBlock
@@ -274,24 +295,27 @@ def dilated_forward(x, p: DilParams, training, save=True, stats_hook=None):
     return out, dict(x=x, cat=cat, out=out, p=p, s=s, mean=mean, invstd=invstd)
 
 
-def dilated_backward(ctx, dout, need_dx=True):
+def dilated_backward(ctx, dout, sink, pre="", need_dx=True):
     p: DilParams = ctx["p"]
     x, cat, out = ctx["x"], ctx["cat"], ctx["out"]
     q = p.w[0].shape[3]
-    sm = Small(x.device)
-    g = {}
-    dcat, sums = bn_backward(dout, cat, ctx["mean"], ctx["invstd"], ctx["s"], sm, act=out, mask=None)
+    cin = x.shape[3]
     c = 4 * q
-    g["bn.bias"], g["bn.weight"] = sums[:c], sums[c:]
+    # parameter order: conv1.weight, conv1.bias, ..., conv4.bias, bn.weight, bn.bias
+    wb = [sink.buf(pre, [(f"conv{i + 1}.weight", (1 if i == 0 else 3, 1 if i == 0 else 3, cin, q)), (f"conv{i + 1}.bias", (q,))])
+          for i in range(4)]
+    sums = sink.buf(pre, [("bn.weight", (c,)), ("bn.bias", (c,))])
+    dcat = bn_backward(dout, cat, ctx["mean"], ctx["invstd"], ctx["s"], sums, act=out, mask=None)
     dx = None
     for i in range(4):
         sl = dcat[..., i * q:(i + 1) * q]
         k = 1 if i == 0 else 3
-        g[f"conv{i + 1}.weight"] = ops.conv_wgrad(x, sl, k, k, dil=DIL[i])
-        g[f"conv{i + 1}.bias"] = chan_sum(sl, sm)
+        nw = k * k * cin * q
+        ops.conv_wgrad(x, sl, k, k, dil=DIL[i], out=wb[i][:nw])
+        chan_sum(sl, wb[i][nw:])
         if need_dx:
             dx = ops.conv_dgrad(sl, p.w[i], out=dx, dil=DIL[i], accumulate=i > 0)
-    return dx, g
+    return dx
 
 
 # =============================================================================== up-conv + attention gate + concat
@@ -322,39 +346,41 @@ def gate_forward(up, skip, p: UpGateParams, training, att_out, sm, stats_hook=No
                 sp=sp, hp=hp, mean_p=mean_p, invstd_p=invstd_p)
 
 
-def gate_backward(gc, up, skip, p: UpGateParams, datt, dup, sm, pre=""):
-    """datt: grad of the gated skip (view); dup: grad buffer of `up`, accumulated into.  -> (dskip, grads)"""
+def gate_backward(gc, up, skip, p: UpGateParams, datt, dup, sink, pre=""):
+    """datt: grad of the gated skip (view); dup: grad buffer of `up`, accumulated into.  -> dskip"""
     n, h, w, c = skip.shape
     f = p.wg.shape[3]
+    cg = up.shape[3]
     P = n * h * w
     st = ops.stream()
     dev = skip.device
-    g = {}
+    # parameter order: W_g.0.weight, W_g.0.bias, W_g.1.weight, W_g.1.bias, W_x.0.*, W_x.1.*, psi.0.weight, psi.0.bias, psi.1.*
+    wg_b = sink.buf(pre, [("W_g.0.weight", (1, 1, cg, f)), ("W_g.0.bias", (f,))])
+    sums_g = sink.buf(pre, [("W_g.1.weight", (f,)), ("W_g.1.bias", (f,))])
+    wx_b = sink.buf(pre, [("W_x.0.weight", (1, 1, c, f)), ("W_x.0.bias", (f,))])
+    sums_x = sink.buf(pre, [("W_x.1.weight", (f,)), ("W_x.1.bias", (f,))])
+    dwpsi_db = sink.buf(pre, [("psi.0.weight", (1, 1, f, 1)), ("psi.0.bias", (1,))])
+    sums_p = sink.buf(pre, [("psi.1.weight", (1,)), ("psi.1.bias", (1,))])
     dskip = ops.empty_nhwc(n, h, w, c, skip)
     dsbn = torch.empty((n, h, w, 1), device=dev, dtype=torch.float32)
     check(lib.runet_ag_bwd1(datt.data_ptr(), ops.ld(datt), skip.data_ptr(), ops.ld(skip), gc["s"].data_ptr(), gc["sp"].data_ptr(),
                             gc["hp"].data_ptr(), dskip.data_ptr(), ops.ld(dskip), dsbn.data_ptr(), P, c, st))
-    ds, sums_p = bn_backward(dsbn, gc["s"], gc["mean_p"], gc["invstd_p"], gc["sp"], sm, out=dsbn)
-    g[pre + "psi.1.bias"], g[pre + "psi.1.weight"] = sums_p[:1], sums_p[1:]
+    ds = bn_backward(dsbn, gc["s"], gc["mean_p"], gc["invstd_p"], gc["sp"], sums_p, out=dsbn)
     dpre = ops.empty_nhwc(n, h, w, f, skip)
-    dwpsi_db = sm.f(f + 1)
     ws = _ws(n, h * w, f, dev)
     check(lib.runet_ag_bwd2(ds.data_ptr(), gc["g1"].data_ptr(), ops.ld(gc["g1"]), gc["x1"].data_ptr(), ops.ld(gc["x1"]), gc["sg"].data_ptr(),
                             gc["hg"].data_ptr(), gc["sx"].data_ptr(), gc["hx"].data_ptr(), p.wpsi.data_ptr(), dpre.data_ptr(), ops.ld(dpre),
                             ws.data_ptr(), dwpsi_db.data_ptr(), P, f, st))
-    g[pre + "psi.0.weight"], g[pre + "psi.0.bias"] = dwpsi_db[:f].view(1, 1, f, 1), dwpsi_db[f:]
-    dg1, sums_g = bn_backward(dpre, gc["g1"], gc["mean_g"], gc["invstd_g"], gc["sg"], sm)
-    g[pre + "W_g.1.bias"], g[pre + "W_g.1.weight"] = sums_g[:f], sums_g[f:]
-    g[pre + "W_g.0.weight"] = ops.conv_wgrad(up, dg1, 1, 1)
-    g[pre + "W_g.0.bias"] = chan_sum(dg1, sm)
+    dg1 = bn_backward(dpre, gc["g1"], gc["mean_g"], gc["invstd_g"], gc["sg"], sums_g)
+    ops.conv_wgrad(up, dg1, 1, 1, out=wg_b[:cg * f])
+    chan_sum(dg1, wg_b[cg * f:])
     ops.conv_dgrad(dg1, p.wg, out=dup, accumulate=True)
     del dg1
-    dx1, sums_x = bn_backward(dpre, gc["x1"], gc["mean_x"], gc["invstd_x"], gc["sx"], sm, out=dpre)
-    g[pre + "W_x.1.bias"], g[pre + "W_x.1.weight"] = sums_x[:f], sums_x[f:]
-    g[pre + "W_x.0.weight"] = ops.conv_wgrad(skip, dx1, 1, 1)
-    g[pre + "W_x.0.bias"] = chan_sum(dx1, sm)
+    dx1 = bn_backward(dpre, gc["x1"], gc["mean_x"], gc["invstd_x"], gc["sx"], sums_x, out=dpre)
+    ops.conv_wgrad(skip, dx1, 1, 1, out=wx_b[:c * f])
+    chan_sum(dx1, wx_b[c * f:])
     ops.conv_dgrad(dx1, p.wx, out=dskip, accumulate=True)
-    return dskip, g
+    return dskip
 
 
 def upgate_forward(y, skip, p: UpGateParams, training, save=True, stats_hook=None):
@@ -371,18 +397,19 @@ def upgate_forward(y, skip, p: UpGateParams, training, save=True, stats_hook=Non
     return cat, gc
 
 
-def upgate_backward(ctx, dcat):
-    """dcat [N,H,W,2C] is consumed (its right half accumulates the gate's gradient).  -> (dy, dskip, grads)"""
+def upgate_backward(ctx, dcat, sink, pre_att, pre_up):
+    """dcat [N,H,W,2C] is consumed (its right half accumulates the gate's gradient).  -> (dy, dskip)"""
     p: UpGateParams = ctx["p"]
     y, skip, cat = ctx["y"], ctx["skip"], ctx["cat"]
     c = skip.shape[3]
-    sm = Small(skip.device)
+    cin = y.shape[3]
     up, dup, datt = cat[..., c:], dcat[..., c:], dcat[..., :c]
-    dskip, g = gate_backward(ctx, up, skip, p, datt, dup, sm, pre="att.")
-    g["up.weight"] = ops.convt_wgrad(y, dup)
-    g["up.bias"] = chan_sum(dup, sm)
+    dskip = gate_backward(ctx, up, skip, p, datt, dup, sink, pre=pre_att)
+    up_b = sink.buf(pre_up, [("weight", (2, 2, cin, c)), ("bias", (c,))])
+    ops.convt_wgrad(y, dup, out=up_b[:4 * cin * c])
+    chan_sum(dup, up_b[4 * cin * c:])
     dy = ops.convt_dgrad(dup, p.wup)
-    return dy, dskip, g
+    return dy, dskip
 
 
 # =============================================================================== pool / stem / head
@@ -421,11 +448,11 @@ def outc_forward(x, w, b, want_logit=False):
     return prob, logit
 
 
-def outc_backward(dprob, prob, x, w):
+def outc_backward(dprob, prob, x, w, sink, pre=""):
     n, h, wd, c = x.shape
     dx = ops.empty_nhwc(n, h, wd, c, x)
-    dw_db = torch.empty(c + 1, device=x.device, dtype=torch.float32)
+    dw_db = sink.buf(pre, [("weight", (1, 1, c, 1)), ("bias", (1,))])
     ws = _ws(n, h * wd, c, x.device)
     check(lib.runet_outc_bwd(dprob.data_ptr(), prob.data_ptr(), x.data_ptr(), ops.ld(x), w.data_ptr(), dx.data_ptr(), ops.ld(dx), ws.data_ptr(),
                              dw_db.data_ptr(), n * h * wd, c, ops.stream()))
-    return dx, dw_db[:c].view(1, 1, c, 1), dw_db[c:]
+    return dx

@@ -378,7 +378,7 @@ __global__ void ca_bwd_final_kernel(const float* __restrict__ sdu, const float* 
             s0 += c_ * du + da + dm;
             s1 += (c_ * (dut - mu * du) + da * ((double)mean_nc[k] - mu) + dm * ((double)tval[k] - mu)) * is;
         }
-        sums2[i] = (float)s0; sums2[C + i] = (float)s1;
+        sums2[i] = (float)s1; sums2[C + i] = (float)s0;   // [dgamma | dbeta]
     }
 }
 
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(TPB) void rb_bwd3_kernel(const float* __restrict__ 
             const float du = d[q] * v + g0 + ((c + q) == am ? g1 : 0.f);
             const float du0 = du * ca[k] + davg[k] * invHW + (idx[k] == hw ? dmx[k] : 0.f);
             const float xh = (t[q] - mean2[c + q]) * invstd2[c + q];
-            r[q] = s2[c + q] * (du0 - sums2[c + q] * inv_m - xh * sums2[C + c + q] * inv_m);
+            r[q] = s2[c + q] * (du0 - sums2[C + c + q] * inv_m - xh * sums2[c + q] * inv_m);
         }
         *reinterpret_cast<f32x4*>(dt2 + p * lddt + c) = r;
     }

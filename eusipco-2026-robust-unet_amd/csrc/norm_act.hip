@@ -265,8 +265,8 @@ __global__ void bn_bwd_reduce_final(const float* __restrict__ part, int nparts, 
     if (c >= C) return;
     double a = 0, b = 0;
     for (int k = 0; k < nparts; ++k) { a += part[((long)k * C + c) * 2]; b += part[((long)k * C + c) * 2 + 1]; }
-    sums[c] = (float)a;        // dbeta  = sum g
-    sums[C + c] = (float)b;    // dgamma = sum g * xhat
+    sums[c] = (float)b;        // dgamma = sum g * xhat   (laid out like the parameters: weight, then bias)
+    sums[C + c] = (float)a;    // dbeta  = sum g
 }
 
 template <int VEC>
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const float* __restri
             float gg = g[q];
             if (act) gg = (av[q] > 0.f) ? gg * (mask ? mask[(long)n * C + c + q] : 1.f) : 0.f;
             const float xh = (xv[q] - mean[c + q]) * invstd[c + q];
-            r[q] = scale[c + q] * (gg - sums[c + q] * inv_m - xh * sums[C + c + q] * inv_m);
+            r[q] = scale[c + q] * (gg - sums[C + c + q] * inv_m - xh * sums[c + q] * inv_m);
         }
         if constexpr (VEC == 4) {
             f32x4 t = {r[0], r[1], r[2], r[3]};

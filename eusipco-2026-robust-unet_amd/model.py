@@ -187,11 +187,12 @@ class _GateFn(torch.autograd.Function):
     def backward(ctx, dout):
         gn, xn = ctx.io
         dup = torch.zeros(gn.shape, device=gn.device, dtype=torch.float32)
-        dskip, g = B.gate_backward(ctx.gc, gn, xn, ctx.p, _nhwc(dout), dup, B.Small(gn.device))
+        sink = B.DictSink(gn.device)
+        dskip = B.gate_backward(ctx.gc, gn, xn, ctx.p, _nhwc(dout), dup, sink)
         ctx.gc = None
         names = ["W_g.0.weight", "W_g.0.bias", "W_g.1.weight", "W_g.1.bias", "W_x.0.weight", "W_x.0.bias", "W_x.1.weight",
                  "W_x.1.bias", "psi.0.weight", "psi.0.bias", "psi.1.weight", "psi.1.bias"]
-        return (_nchw(dup), _nchw(dskip), None) + tuple(_logical(k, g[k]) for k in names)
+        return (_nchw(dup), _nchw(dskip), None) + tuple(_logical(k, sink.g[k]) for k in names)
 
 
 def _logical(name, t):
@@ -265,11 +266,12 @@ class _RBFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        dx, g = B.rb_backward(ctx.c, _nhwc(dout), need_dx=ctx.need_dx)
+        sink = B.DictSink(dout.device)
+        dx = B.rb_backward(ctx.c, _nhwc(dout), sink, need_dx=ctx.need_dx)
         ctx.c = None
         if dx is not None:
             dx = _nchw(dx[..., :ctx.cin]) if dx.shape[3] != ctx.cin else _nchw(dx)
-        return (dx, None) + tuple(_logical(k, g[k]) for k in ctx.names)
+        return (dx, None) + tuple(_logical(k, sink.g[k]) for k in ctx.names)
 
 
 # ----------------------------------------------------------------------------- DilatedBlock
@@ -309,9 +311,10 @@ class _DilFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        dx, g = B.dilated_backward(ctx.c, _nhwc(dout), need_dx=ctx.need_dx)
+        sink = B.DictSink(dout.device)
+        dx = B.dilated_backward(ctx.c, _nhwc(dout), sink, need_dx=ctx.need_dx)
         ctx.c = None
-        return (_nchw(dx) if dx is not None else None, None) + tuple(_logical(k, g[k]) for k in ctx.names)
+        return (_nchw(dx) if dx is not None else None, None) + tuple(_logical(k, sink.g[k]) for k in ctx.names)
 
 
 class MaxPool2d(nn.Module):
@@ -371,6 +374,7 @@ class RobustUNet(nn.Module):
         self.dec1 = ResidualBlock(b * 2, b, dropout_rate=0.1)
         self.outc = nn.Sequential(Conv2d(b, n_classes, 1), _Act())
         self.sync_bn_hook = None     # set by ddp.GradAllReducer(sync_bn=True)
+        self._arena = None
         self._initialize_weights()
 
     def _initialize_weights(self):
@@ -385,6 +389,13 @@ class RobustUNet(nn.Module):
     def _rbs(self):
         return {"inc": self.inc, "down1.1": self.down1[1], "down2.1": self.down2[1], "down3.1": self.down3[1],
                 "bottleneck.2": self.bottleneck[2], "dec4": self.dec4, "dec3": self.dec3, "dec2": self.dec2, "dec1": self.dec1}
+
+    def grad_arena(self):
+        """The flat gradient buffer (created on first use, rebuilt if the parameters moved device)."""
+        dev = self.outc[0].weight.device
+        if self._arena is None or self._arena.device != dev:
+            self._arena = GradArena(self)
+        return self._arena
 
     def set_dropout_masks(self, masks):
         """masks: {block prefix: [N, C] keep-mask already divided by 1-p} or None to restore random draws."""
@@ -434,49 +445,94 @@ def net_forward(net: RobustUNet, x, save, want_logit=False):
     return prob, logit, (C if save else None)
 
 
-def net_backward(C, dprob):
-    """-> {full parameter name: gradient in the parameter's own (logical shape, physical strides)}"""
-    G = {}
+# backward completes the blocks in this order; the gradient arena is laid out the same way, so that
+# "everything up to block k" is one contiguous range (RCCL buckets are slices of it, no packing copies)
+BACKWARD_ORDER = ("outc.0", "dec1", "att1", "up1", "dec2", "att2", "up2", "dec3", "att3", "up3", "dec4", "att4", "up4",
+                  "bottleneck.2", "bottleneck.1", "down3.1", "down2.1", "down1.1", "inc")
 
-    def put(prefix, g, ren=None):
-        for k, v in g.items():
-            if ren:
-                for a, b_ in ren.items():
-                    if k.startswith(a):
-                        k = b_ + k[len(a):]
-                        break
-                G[k] = _logical(k, v)
-            else:
-                G[f"{prefix}.{k}"] = _logical(k, v)
 
+class GradArena:
+    """One flat fp32 buffer holding every parameter gradient, in backward-completion order.
+
+    `p.grad` of each parameter is a view into it (same logical shape / physical strides as the
+    parameter).  Each tensor starts on a 16-byte boundary, except a `.bias` that directly follows
+    the `.weight` of the same module, which is packed right behind it (the BN / psi / outc kernels
+    write the pair as one vector)."""
+
+    def __init__(self, net):
+        named = list(net.named_parameters())
+        self.device = named[0][1].device
+        self.off, self.numel, self.block_end = {}, {}, {}
+        cur, seen = 0, set()
+        for blk in BACKWARD_ORDER:
+            prev = None
+            for name, p in named:
+                if not name.startswith(blk + "."):
+                    continue
+                packed = prev is not None and name.endswith(".bias") and prev == name[:-5] + ".weight"
+                if not packed:
+                    cur = (cur + 3) // 4 * 4
+                self.off[name], self.numel[name] = cur, p.numel()
+                cur += p.numel()
+                prev = name
+                seen.add(name)
+            self.block_end[blk] = cur
+        assert len(seen) == len(named), "BACKWARD_ORDER does not cover every parameter"
+        self.total = (cur + 3) // 4 * 4
+        self.flat = torch.zeros(self.total, device=self.device, dtype=torch.float32)
+        self.on_block_done = None        # ddp.GradAllReducer hook: f(end_offset_in_floats)
+
+    def buf(self, prefix, items):
+        off0 = self.off[prefix + items[0][0]]
+        cur = off0
+        for name, sh in items:
+            n = B._numel(sh)
+            assert self.off[prefix + name] == cur and self.numel[prefix + name] == n, f"arena layout mismatch at {prefix + name}"
+            cur += n
+        return self.flat[off0:cur]
+
+    def grad_view(self, name, p):
+        return torch.as_strided(self.flat, p.shape, p.stride(), self.off[name])
+
+    def done(self, blk):
+        if self.on_block_done is not None:
+            self.on_block_done(self.block_end[blk])
+
+
+def net_backward(C, dprob, sink, done=lambda blk: None):
+    """Explicit backward pass; parameter gradients are written through `sink` (GradArena or DictSink)."""
     y, w, prob = C["head"]
-    dy, dw, db = B.outc_backward(dprob, prob, y, w)
-    G["outc.0.weight"], G["outc.0.bias"] = _logical("outc.0.weight", dw), db
+    dy = B.outc_backward(dprob, prob, y, w, sink, pre="outc.0.")
+    done("outc.0")
     dskip = {}
     for lvl in (1, 2, 3, 4):
-        dcat, g = B.rb_backward(C[f"dec{lvl}"], dy)
-        put(f"dec{lvl}", g)
-        dy, dskip[lvl], g = B.upgate_backward(C[f"upgate{lvl}"], dcat)
-        put("", g, ren={"att.": f"att{lvl}.", "up.": f"up{lvl}."})
-    dxd, g = B.rb_backward(C["bottleneck.2"], dy)
-    put("bottleneck.2", g)
-    dpool, g = B.dilated_backward(C["bottleneck.1"], dxd)
-    put("bottleneck.1", g)
+        dcat = B.rb_backward(C[f"dec{lvl}"], dy, sink, pre=f"dec{lvl}.")
+        done(f"dec{lvl}")
+        dy, dskip[lvl] = B.upgate_backward(C[f"upgate{lvl}"], dcat, sink, f"att{lvl}.", f"up{lvl}.")
+        done(f"up{lvl}")
+    dxd = B.rb_backward(C["bottleneck.2"], dy, sink, pre="bottleneck.2.")
+    done("bottleneck.2")
+    dpool = B.dilated_backward(C["bottleneck.1"], dxd, sink, pre="bottleneck.1.")
+    done("bottleneck.1")
     dcur = B.maxpool_backward(dpool, C["pool4"], dx=dskip[4])
     for lvl in (3, 2, 1):
-        dpool, g = B.rb_backward(C[f"down{lvl}.1"], dcur)
-        put(f"down{lvl}.1", g)
+        dpool = B.rb_backward(C[f"down{lvl}.1"], dcur, sink, pre=f"down{lvl}.1.")
+        done(f"down{lvl}.1")
         dcur = B.maxpool_backward(dpool, C[f"pool{lvl}"], dx=dskip[lvl])
-    _, g = B.rb_backward(C["inc"], dcur, need_dx=False)
-    put("inc", g)
-    return G
+    B.rb_backward(C["inc"], dcur, sink, pre="inc.", need_dx=False)
+    done("inc")
 
 
 class _NetFn(torch.autograd.Function):
+    """The whole network as one autograd node.  Its backward writes the parameter gradients straight into the
+    model's GradArena and assigns `p.grad` itself (returning None to autograd for the parameters): no
+    per-tensor accumulate kernels, gradients stay contiguous for RCCL and the fused optimizer.  If some
+    `p.grad` is already populated (gradient accumulation), the new gradients are added to it instead."""
+
     @staticmethod
     def forward(ctx, x, net, names, want_logit, *params):
         prob, logit, C = net_forward(net, x, save=True, want_logit=want_logit)
-        ctx.C, ctx.names = C, names
+        ctx.C, ctx.net = C, net
         if logit is None:
             logit = prob.new_empty(0)
         ctx.mark_non_differentiable(logit)
@@ -486,6 +542,24 @@ class _NetFn(torch.autograd.Function):
     def backward(ctx, dprob, _dlogit):
         if ctx.C is None:
             raise RuntimeError("RobustUNet backward called twice (activations were released after the first pass)")
-        G = net_backward(ctx.C, dprob.contiguous())
+        net = ctx.net
+        named = list(net.named_parameters())
+        arena = net.grad_arena()
+        if all(p.grad is None for _, p in named):
+            net_backward(ctx.C, dprob.contiguous(), arena, arena.done)
+            for k, p in named:
+                if p.requires_grad:
+                    p.grad = arena.grad_view(k, p)
+        else:
+            sink = B.DictSink(dprob.device)
+            net_backward(ctx.C, dprob.contiguous(), sink)
+            for k, p in named:
+                if not p.requires_grad:
+                    continue
+                g = _logical(k, sink.g[k])
+                if p.grad is None:
+                    p.grad = g
+                else:
+                    p.grad.add_(g)
         ctx.C = None
-        return (None, None, None, None) + tuple(G[k] for k in ctx.names)
+        return (None, None, None, None) + (None,) * len(named)

@@ -54,14 +54,53 @@ def hwio_t(w):
     return v if v.is_contiguous() else v.contiguous()
 
 
+# ---- optional live timing of the implicit-GEMM launches (bench.py roofline): HIP events on the launch stream
+_PROFILE = None
+
+
+def start_conv_profile():
+    global _PROFILE
+    _PROFILE = []
+    return _PROFILE
+
+
+def stop_conv_profile(prof):
+    """-> dict(kernel=dominant instantiation, tflops, avg_us, launches, time_s, by_kernel={name: [launches, ms, TFLOP/s]})"""
+    global _PROFILE
+    _PROFILE = None
+    torch.cuda.synchronize()
+    agg = {}
+    for name, flops, e0, e1 in prof:
+        a = agg.setdefault(name, [0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += e0.elapsed_time(e1) * 1e-3
+        a[2] += flops
+    dom = max(agg, key=lambda k: agg[k][1])
+    n, t, f = agg[dom]
+    by = {k: [v[0], round(v[1] * 1e3, 3), round(v[2] / v[1] / 1e12, 2)] for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
+    return {"kernel": dom, "tflops": f / t / 1e12, "avg_us": t / n * 1e6, "launches": n, "time_s": t, "by_kernel": by}
+
+
+def _igemm(mode, x, ldx, w, bias, y, ldy, n, h, wd, cin, cin_w, cout, kh, kw, dil, accumulate):
+    if _PROFILE is None:
+        check(lib.runet_conv_igemm(x, ldx, w, bias, y, ldy, n, h, wd, cin, cin_w, cout, kh, kw, dil, mode, accumulate, stream()))
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    check(lib.runet_conv_igemm(x, ldx, w, bias, y, ldy, n, h, wd, cin, cin_w, cout, kh, kw, dil, mode, accumulate, stream()))
+    e1.record()
+    taps = 4 if kh == 2 else kh * kw
+    name = lib.runet_conv_igemm_kernel_name(n, h, wd, cout, mode).decode()
+    _PROFILE.append((name, 2.0 * n * h * wd * taps * min(cin, cin_w) * cout, e0, e1))
+
+
 def conv_fwd(x, w_hwio, bias=None, out=None, dil=1, accumulate=False):
     n, h, w, cin = x.shape
     kh, kw, cin_w, cout = w_hwio.shape
     if out is None:
         out = empty_nhwc(n, h, w, cout, x)
-    check(lib.runet_conv_igemm(x.data_ptr(), ld(x), w_hwio.data_ptr(), bias.data_ptr() if bias is not None else None,
-                               out.data_ptr(), ld(out), n, h, w, cin, cin_w, cout, kh, kw, dil, CONV_FWD,
-                               int(accumulate), stream()))
+    _igemm(CONV_FWD, x.data_ptr(), ld(x), w_hwio.data_ptr(), bias.data_ptr() if bias is not None else None,
+           out.data_ptr(), ld(out), n, h, w, cin, cin_w, cout, kh, kw, dil, int(accumulate))
     return out
 
 
@@ -71,8 +110,8 @@ def conv_dgrad(dy, w_hwio, out=None, dil=1, accumulate=False):
     assert cout_w == cout
     if out is None:
         out = empty_nhwc(n, h, w, cin, dy)
-    check(lib.runet_conv_igemm(dy.data_ptr(), ld(dy), w_hwio.data_ptr(), None, out.data_ptr(), ld(out), n, h, w,
-                               cout, cout, cin, kh, kw, dil, CONV_DGRAD, int(accumulate), stream()))
+    _igemm(CONV_DGRAD, dy.data_ptr(), ld(dy), w_hwio.data_ptr(), None, out.data_ptr(), ld(out), n, h, w,
+           cout, cout, cin, kh, kw, dil, int(accumulate))
     return out
 
 
@@ -94,8 +133,8 @@ def convt_fwd(x, w_hwio, bias=None, out=None):
     _, _, cin_w, cout = w_hwio.shape
     if out is None:
         out = empty_nhwc(n, 2 * h, 2 * w, cout, x)
-    check(lib.runet_conv_igemm(x.data_ptr(), ld(x), w_hwio.data_ptr(), bias.data_ptr() if bias is not None else None,
-                               out.data_ptr(), ld(out), n, h, w, cin, cin_w, cout, 2, 2, 1, CONVT_FWD, 0, stream()))
+    _igemm(CONVT_FWD, x.data_ptr(), ld(x), w_hwio.data_ptr(), bias.data_ptr() if bias is not None else None,
+           out.data_ptr(), ld(out), n, h, w, cin, cin_w, cout, 2, 2, 1, 0)
     return out
 
 
@@ -105,8 +144,8 @@ def convt_dgrad(dy, w_hwio, out=None, accumulate=False):
     h, w = h2 // 2, w2 // 2
     if out is None:
         out = empty_nhwc(n, h, w, cin, dy)
-    check(lib.runet_conv_igemm(dy.data_ptr(), ld(dy), w_hwio.data_ptr(), None, out.data_ptr(), ld(out), n, h, w,
-                               cout, cout, cin, 2, 2, 1, CONVT_DGRAD, int(accumulate), stream()))
+    _igemm(CONVT_DGRAD, dy.data_ptr(), ld(dy), w_hwio.data_ptr(), None, out.data_ptr(), ld(out), n, h, w,
+           cout, cout, cin, 2, 2, 1, int(accumulate))
     return out
 
 

@@ -41,6 +41,10 @@ int runet_conv_igemm(const float* x, int ldx, const float* w, const float* bias,
                      int n_img, int h, int w_, int cin, int cin_w, int cout, int kh, int kw, int dil,
                      int mode, int accumulate, void* stream);
 
+/* name of the kernel instantiation runet_conv_igemm launches for this shape (as rocprofv3 prints it, minus the
+ * namespace), so that bench.py's live timings can be matched with the profiler's per-kernel rows */
+const char* runet_conv_igemm_kernel_name(int n_img, int h, int w_, int cout, int mode);
+
 /* dw[kh,kw,cin_w,cout] = sum_pixels x (x) dy  (weight gradient; transposed != 0: dy is [n,2h,2w,cout]
  * and the 2x2 taps index the dy pixel).  `workspace` (>= runet_conv_wgrad_workspace_floats floats, may be
  * NULL) holds split-K partial slabs that are summed in a fixed order. */
@@ -71,10 +75,10 @@ int runet_bn_apply(const float* x, int ldx, float* y, int ldy, long pixels, int 
                    const float* mask_nc, int relu, void* stream);
 
 /* g = dy, or dy*mask_nc[n,c]*(act > 0) when act != NULL (act = saved output of relu/dropout).
- * sums[0:c] = sum g (= dbeta), sums[c:2c] = sum g*xhat (= dgamma). */
+ * sums[0:c] = sum g*xhat (= dgamma), sums[c:2c] = sum g (= dbeta): the order of (weight, bias). */
 int runet_bn_bwd_reduce(const float* dy, int lddy, const float* x, int ldx, const float* act, int ldact, int n_img, int hw, int c,
                         const float* mean, const float* invstd, const float* mask_nc, float* workspace, float* sums, void* stream);
-/* dx = scale*(g - sums[c]/M - xhat*sums[C+c]/M), M = pixels */
+/* dx = scale*(g - sums[C+c]/M - xhat*sums[c]/M), M = pixels */
 int runet_bn_bwd_apply(const float* dy, int lddy, const float* x, int ldx, const float* act, int ldact, float* dx, int lddx,
                        long pixels, int hw, int c, const float* mean, const float* invstd, const float* scale, const float* sums,
                        const float* mask_nc, void* stream);
