@@ -372,6 +372,187 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WGradArgs g) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------ wgrad, tile-resident form
+// For 3x3 (dilation 1) and 1x1 convolutions: a block keeps a 4x16-pixel tile of dy and the matching x tile (with its
+// 1-pixel halo for 3x3) in LDS and accumulates ALL taps from it, so x and dy are read from HBM/L2 once per
+// (cin-chunk, cout-chunk) pair instead of once per tap; it then walks `tiles_per_split` tiles with the accumulators in
+// registers (9 taps x one 32x32 tile per wave = 144 accumulator registers for 3x3) and writes one partial slab.
+// The next tile's global loads are issued before the current tile's MFMAs (register prefetch).
+struct WGradTileArgs {
+    const float* x; int ldx;
+    const float* dy; int ldy;
+    float* out;                 // slabs [split][KS*KS][Kvalid][Nco]
+    int Kci, Kvalid, Nco;
+    int Nimg, H, W;
+    int tiles_h, tiles_w, total_tiles, tiles_per_split, co_chunks;
+};
+
+template <int KS, int TM, int TN>
+__global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(WGradTileArgs g) {
+    constexpr int CI = 64 * TM, CO = 64 * TN;
+    constexpr int TH = 4, TW = 16, NPX = TH * TW;
+    constexpr int HALO = (KS == 3) ? 1 : 0;
+    constexpr int HTW = TW + 2 * HALO, HTH = TH + 2 * HALO, NHPX = HTW * HTH;
+    constexpr int XQ = CI / 4, YQ = CO / 4;
+    constexpr int NXV = (NHPX * XQ + 255) / 256, NYV = (NPX * YQ + 255) / 256;
+    constexpr int NT = KS * KS;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xs = smem;
+    float* dys = smem + NHPX * CI;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1, li = lane & 31, lh = lane >> 5;
+    const int ci0 = (blockIdx.x / g.co_chunks) * CI, co0 = (blockIdx.x % g.co_chunks) * CO;
+    const int t_begin = blockIdx.y * g.tiles_per_split;
+    const int t_end = min(g.total_tiles, t_begin + g.tiles_per_split);
+    const long P = (long)g.Nimg * g.H * g.W;
+    const int tiles_per_img = g.tiles_h * g.tiles_w;
+
+    f32x4 rx[NXV], ry[NYV];
+    auto prefetch = [&](int t) {
+        int n = 0, h0 = 0, w0 = 0;
+        if constexpr (KS == 3) {
+            n = t / tiles_per_img;
+            const int rem = t - n * tiles_per_img;
+            const int th = rem / g.tiles_w;
+            h0 = th * TH; w0 = (rem - th * g.tiles_w) * TW;
+        }
+#pragma unroll
+        for (int v = 0; v < NXV; ++v) {
+            const int idx = tid + 256 * v;
+            f32x4 val = {0.f, 0.f, 0.f, 0.f};
+            if (idx < NHPX * XQ) {
+                const int px = idx / XQ, cq = idx % XQ;
+                if (ci0 + cq * 4 < g.Kci) {
+                    if constexpr (KS == 3) {
+                        const int hy = px / HTW, hx = px - hy * HTW;
+                        const int ih = h0 - 1 + hy, iw = w0 - 1 + hx;
+                        if ((unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W)
+                            val = *reinterpret_cast<const f32x4*>(g.x + (((long)n * g.H + ih) * g.W + iw) * g.ldx + ci0 + cq * 4);
+                    } else {
+                        const long p = (long)t * NPX + px;
+                        if (p < P) val = *reinterpret_cast<const f32x4*>(g.x + p * g.ldx + ci0 + cq * 4);
+                    }
+                }
+            }
+            rx[v] = val;
+        }
+#pragma unroll
+        for (int v = 0; v < NYV; ++v) {
+            const int idx = tid + 256 * v;
+            f32x4 val = {0.f, 0.f, 0.f, 0.f};
+            if (idx < NPX * YQ) {
+                const int px = idx / YQ, cq = idx % YQ;
+                if (co0 + cq * 4 < g.Nco) {
+                    if constexpr (KS == 3) {
+                        const int oh = h0 + (px >> 4), ow = w0 + (px & 15);
+                        if (oh < g.H && ow < g.W)
+                            val = *reinterpret_cast<const f32x4*>(g.dy + (((long)n * g.H + oh) * g.W + ow) * g.ldy + co0 + cq * 4);
+                    } else {
+                        const long p = (long)t * NPX + px;
+                        if (p < P) val = *reinterpret_cast<const f32x4*>(g.dy + p * g.ldy + co0 + cq * 4);
+                    }
+                }
+            }
+            ry[v] = val;
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int v = 0; v < NXV; ++v) {
+            const int idx = tid + 256 * v;
+            if (idx < NHPX * XQ) *reinterpret_cast<f32x4*>(xs + idx * 4) = rx[v];
+        }
+#pragma unroll
+        for (int v = 0; v < NYV; ++v) {
+            const int idx = tid + 256 * v;
+            if (idx < NPX * YQ) *reinterpret_cast<f32x4*>(dys + idx * 4) = ry[v];
+        }
+    };
+
+    f32x16 acc[NT][TM][TN];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][a][b][r] = 0.f;
+
+    if (t_begin < t_end) prefetch(t_begin);
+    for (int t = t_begin; t < t_end; ++t) {
+        __syncthreads();
+        stash();
+        __syncthreads();
+        if (t + 1 < t_end) prefetch(t + 1);
+#pragma unroll 2
+        for (int m = 0; m < NPX / 2; ++m) {
+            const int p = 2 * m + lh;
+            const int ty = p >> 4, tx = p & 15;
+            float bf[TN];
+#pragma unroll
+            for (int b = 0; b < TN; ++b) bf[b] = dys[p * CO + (wc * TN + b) * 32 + li];
+#pragma unroll
+            for (int r = 0; r < KS; ++r)
+#pragma unroll
+                for (int q = 0; q < KS; ++q) {
+                    float af[TM];
+#pragma unroll
+                    for (int a = 0; a < TM; ++a) af[a] = xs[((ty + r) * HTW + tx + q) * CI + (wr * TM + a) * 32 + li];
+#pragma unroll
+                    for (int a = 0; a < TM; ++a)
+#pragma unroll
+                        for (int b = 0; b < TN; ++b)
+                            acc[r * KS + q][a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[r * KS + q][a][b], 0, 0, 0);
+                }
+        }
+    }
+
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        float* slab = g.out + ((long)blockIdx.y * NT + t) * g.Kvalid * g.Nco;
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int co = co0 + (wc * TN + b) * 32 + li;
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ci = ci0 + (wr * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (co < g.Nco && ci < g.Kvalid) slab[(long)ci * g.Nco + co] = acc[t][a][b][r];
+                }
+        }
+    }
+}
+
+struct TilePlan { int tm, tn, ci_chunks, co_chunks, total_tiles, tiles_h, tiles_w, splits, tps; };
+
+static TilePlan wgrad_tile_plan(int n_img, int h, int w_, int cin_w, int cout, int ks) {
+    TilePlan p{};
+    if (ks == 3) { p.tm = 1; p.tn = 1; }
+    else { p.tm = cin_w > 64 ? 2 : 1; p.tn = cout > 64 ? 2 : 1; }
+    p.ci_chunks = cdiv(cin_w, 64 * p.tm);
+    p.co_chunks = cdiv(cout, 64 * p.tn);
+    if (ks == 3) { p.tiles_h = cdiv(h, 4); p.tiles_w = cdiv(w_, 16); p.total_tiles = n_img * p.tiles_h * p.tiles_w; }
+    else { p.tiles_h = p.tiles_w = 0; p.total_tiles = cdiv((long)n_img * h * w_, 64); }
+    const int chunks = p.ci_chunks * p.co_chunks;
+    int splits = cdiv(640, chunks);                 // ~2.5 blocks per CU in total
+    if (splits > p.total_tiles) splits = p.total_tiles;
+    if (splits < 1) splits = 1;
+    p.tps = cdiv(p.total_tiles, splits);
+    p.splits = cdiv(p.total_tiles, p.tps);
+    return p;
+}
+
+template <int KS, int TM, int TN>
+static void launch_wgrad_tile(const WGradTileArgs& a, const TilePlan& p, hipStream_t st) {
+    constexpr int HALO = (KS == 3) ? 1 : 0;
+    const size_t lds = ((size_t)(16 + 2 * HALO) * (4 + 2 * HALO) * 64 * TM + 64 * 64 * TN) * sizeof(float);
+    hipLaunchKernelGGL((wgrad_tile_kernel<KS, TM, TN>), dim3(p.ci_chunks * p.co_chunks, p.splits), dim3(256), lds, st, a);
+}
+
 __global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, long n, int nsplit) {
     const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i >= n) return;
@@ -503,7 +684,19 @@ static void wgrad_plan(long P, int cin_w, int cout, int ntaps, bool& big, int& t
     splits = pick_splits(P, tiles, ntaps);
 }
 
+static bool use_tile_kernel(int kh, int kw, int dil, int transposed) {
+    return !transposed && ((kh == 1 && kw == 1) || (kh == 3 && kw == 3 && dil == 1));
+}
+
 extern "C" long runet_conv_wgrad_workspace_floats(int n_img, int h, int w_, int cin_w, int cout, int kh, int kw) {
+    if (kh == kw && (kh == 1 || kh == 3)) {       // dilation unknown here: take the larger of the two plans
+        const TilePlan p = wgrad_tile_plan(n_img, h, w_, cin_w, cout, kh);
+        bool big; int tiles, splits;
+        wgrad_plan((long)n_img * h * w_, cin_w, cout, kh * kw, big, tiles, splits);
+        const long a = p.splits > 1 ? (long)p.splits * kh * kw * cin_w * cout : 0;
+        const long b = splits > 1 ? (long)splits * kh * kw * cin_w * cout : 0;
+        return a > b ? a : b;
+    }
     bool big; int tiles, splits;
     wgrad_plan((long)n_img * h * w_, cin_w, cout, kh * kw, big, tiles, splits);
     return splits > 1 ? (long)splits * kh * kw * cin_w * cout : 0;
@@ -519,6 +712,28 @@ extern "C" int runet_conv_wgrad(const float* x, int ldx, const float* dy, int ld
     RUNET_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0 && ((uintptr_t)dw % 16) == 0, "pointers must be 16-byte aligned");
     RUNET_REQUIRE((kh == 1 && kw == 1) || (kh == 3 && kw == 3) || (kh == 2 && kw == 2 && transposed), "unsupported kernel size");
     hipStream_t st = (hipStream_t)stream;
+    if (use_tile_kernel(kh, kw, dil, transposed)) {
+        TilePlan p = wgrad_tile_plan(n_img, h, w_, cin_w, cout, kh);
+        const long wsize = (long)kh * kw * cin_w * cout;
+        if (p.splits > 1 && (workspace == nullptr || workspace_floats < p.splits * wsize)) {
+            int s2 = workspace ? (int)(workspace_floats / wsize) : 1;
+            if (s2 < 1) s2 = 1;
+            p.tps = cdiv(p.total_tiles, s2);
+            p.splits = cdiv(p.total_tiles, p.tps);
+        }
+        WGradTileArgs t{};
+        t.x = x; t.ldx = ldx; t.dy = dy; t.ldy = ldy; t.out = (p.splits > 1) ? workspace : dw;
+        t.Kci = cin; t.Kvalid = cin_w; t.Nco = cout; t.Nimg = n_img; t.H = h; t.W = w_;
+        t.tiles_h = p.tiles_h; t.tiles_w = p.tiles_w; t.total_tiles = p.total_tiles; t.tiles_per_split = p.tps; t.co_chunks = p.co_chunks;
+        if (kh == 3) launch_wgrad_tile<3, 1, 1>(t, p, st);
+        else if (p.tm == 2 && p.tn == 2) launch_wgrad_tile<1, 2, 2>(t, p, st);
+        else if (p.tm == 2) launch_wgrad_tile<1, 2, 1>(t, p, st);
+        else if (p.tn == 2) launch_wgrad_tile<1, 1, 2>(t, p, st);
+        else launch_wgrad_tile<1, 1, 1>(t, p, st);
+        if (p.splits > 1)
+            hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(wsize, 256 * 4)), dim3(256), 0, st, workspace, dw, wsize, p.splits);
+        RUNET_CHECK_LAUNCH();
+    }
     WGradArgs a{};
     a.x = x; a.ldx = ldx; a.dy = dy; a.ldy = ldy;
     a.Kci = cin; a.Kvalid = cin_w; a.Nco = cout;

@@ -260,13 +260,22 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_partial(const float* __rest
     }
 }
 
-__global__ void bn_bwd_reduce_final(const float* __restrict__ part, int nparts, int C, float* __restrict__ sums) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// block = CW channels x (256/CW) part-lanes; each thread strides over the partials, LDS tree over the part-lanes
+__global__ __launch_bounds__(TPB) void bn_bwd_reduce_final(const float* __restrict__ part, int nparts, int C, int CW, float* __restrict__ sums) {
+    __shared__ double red[2][TPB];
+    const int PL = TPB / CW;
+    const int cl = threadIdx.x % CW, pl = threadIdx.x / CW;
+    const int c = blockIdx.x * CW + cl;
     double a = 0, b = 0;
-    for (int k = 0; k < nparts; ++k) { a += part[((long)k * C + c) * 2]; b += part[((long)k * C + c) * 2 + 1]; }
-    sums[c] = (float)b;        // dgamma = sum g * xhat   (laid out like the parameters: weight, then bias)
-    sums[C + c] = (float)a;    // dbeta  = sum g
+    if (c < C && pl < PL)
+        for (int k = pl; k < nparts; k += PL) { a += part[((long)k * C + c) * 2]; b += part[((long)k * C + c) * 2 + 1]; }
+    red[0][threadIdx.x] = a; red[1][threadIdx.x] = b;
+    __syncthreads();
+    if (pl == 0 && c < C) {
+        for (int j = 1; j < PL; ++j) { a += red[0][j * CW + cl]; b += red[1][j * CW + cl]; }
+        sums[c] = (float)b;        // dgamma = sum g * xhat   (laid out like the parameters: weight, then bias)
+        sums[C + c] = (float)a;    // dbeta  = sum g
+    }
 }
 
 template <int VEC>
@@ -339,13 +348,23 @@ __global__ __launch_bounds__(TPB) void chan_sum_partial(const float* __restrict_
         part[(long)blockIdx.x * C + c] = (float)a;
     }
 }
-__global__ void chan_sum_final(const float* __restrict__ part, int nparts, int C, float* __restrict__ out, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+__global__ __launch_bounds__(TPB) void chan_sum_final(const float* __restrict__ part, int nparts, int C, int CW, float* __restrict__ out, int accumulate) {
+    __shared__ double red[TPB];
+    const int PL = TPB / CW;
+    const int cl = threadIdx.x % CW, pl = threadIdx.x / CW;
+    const int c = blockIdx.x * CW + cl;
     double a = 0;
-    for (int k = 0; k < nparts; ++k) a += part[(long)k * C + c];
-    out[c] = accumulate ? out[c] + (float)a : (float)a;
+    if (c < C && pl < PL)
+        for (int k = pl; k < nparts; k += PL) a += part[(long)k * C + c];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    if (pl == 0 && c < C) {
+        for (int j = 1; j < PL; ++j) a += red[j * CW + cl];
+        out[c] = accumulate ? out[c] + (float)a : (float)a;
+    }
 }
+
+inline int final_cw(int c) { return c >= 32 ? 32 : c; }
 
 inline int pick_chunks(int N, int HW, int C, int rows) {
     // ~32 vector loads per thread; at least one pass of `rows` pixels per chunk
@@ -438,7 +457,7 @@ extern "C" int runet_bn_bwd_reduce(const float* dy, int lddy, const float* x, in
     dim3 grid(chunks, n_img);
     if (vec == 4) hipLaunchKernelGGL((bn_bwd_reduce_partial<4>), grid, dim3(TPB), lds, st, dy, lddy, x, ldx, act, ldact, hw, c, mean, invstd, mask_nc, ppc, workspace);
     else hipLaunchKernelGGL((bn_bwd_reduce_partial<1>), grid, dim3(TPB), lds, st, dy, lddy, x, ldx, act, ldact, hw, c, mean, invstd, mask_nc, ppc, workspace);
-    hipLaunchKernelGGL(bn_bwd_reduce_final, dim3(cdiv(c, 128)), dim3(128), 0, st, workspace, chunks * n_img, c, sums);
+    hipLaunchKernelGGL(bn_bwd_reduce_final, dim3(cdiv(c, final_cw(c))), dim3(TPB), 0, st, workspace, chunks * n_img, c, final_cw(c), sums);
     RUNET_CHECK_LAUNCH();
 }
 
@@ -467,6 +486,6 @@ extern "C" int runet_chan_sum(const float* x, int ld, long pixels, int c, float*
     const size_t lds = (size_t)rows * c * sizeof(float);
     if (vec == 4) hipLaunchKernelGGL((chan_sum_partial<4>), dim3((int)chunks), dim3(TPB), lds, st, x, ld, pixels, c, ppc, workspace);
     else hipLaunchKernelGGL((chan_sum_partial<1>), dim3((int)chunks), dim3(TPB), lds, st, x, ld, pixels, c, ppc, workspace);
-    hipLaunchKernelGGL(chan_sum_final, dim3(cdiv(c, 128)), dim3(128), 0, st, workspace, (int)chunks, c, out, accumulate);
+    hipLaunchKernelGGL(chan_sum_final, dim3(cdiv(c, final_cw(c))), dim3(TPB), 0, st, workspace, (int)chunks, c, final_cw(c), out, accumulate);
     RUNET_CHECK_LAUNCH();
 }
