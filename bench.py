@@ -96,11 +96,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # rehearsal knobs for a 1-GPU box (never used by the driver): all ranks on cuda:0, collectives over gloo
+    one_device = os.environ.get("RUNET_BENCH_ONE_DEVICE") == "1"
+    backend = os.environ.get("RUNET_BENCH_BACKEND", "nccl")
+    dev_index = 0 if one_device else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     pkg = importlib.import_module(PKG)
     ops = importlib.import_module(PKG + ".ops")

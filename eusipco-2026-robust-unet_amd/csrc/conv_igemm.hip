@@ -553,19 +553,25 @@ static void launch_wgrad_tile(const WGradTileArgs& a, const TilePlan& p, hipStre
     hipLaunchKernelGGL((wgrad_tile_kernel<KS, TM, TN>), dim3(p.ci_chunks * p.co_chunks, p.splits), dim3(256), lds, st, a);
 }
 
-__global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, long n, int nsplit) {
-    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (i >= n) return;
+// out[i] = sum_k slabs[k][i]: block = 32 float4 columns x 8 split-lanes (fixed summation order: reproducible)
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, long n, int nsplit) {
+    __shared__ f32x4 red[256];
+    const int col = threadIdx.x & 31, kl = threadIdx.x >> 5;
+    const long i = ((long)blockIdx.x * 32 + col) * 4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
     if (i + 4 <= n) {
-        f32x4 s = *reinterpret_cast<const f32x4*>(slabs + i);
-        for (int k = 1; k < nsplit; ++k) s += *reinterpret_cast<const f32x4*>(slabs + (long)k * n + i);
-        *reinterpret_cast<f32x4*>(out + i) = s;
-    } else {
-        for (long j = i; j < n; ++j) {
-            float s = slabs[j];
-            for (int k = 1; k < nsplit; ++k) s += slabs[(long)k * n + j];
-            out[j] = s;
-        }
+        for (int k = kl; k < nsplit; k += 8) s += *reinterpret_cast<const f32x4*>(slabs + (long)k * n + i);
+    } else if (i < n) {
+        for (int k = kl; k < nsplit; k += 8)
+            for (int e = 0; e < 4 && i + e < n; ++e) s[e] += slabs[(long)k * n + i + e];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (kl == 0 && i < n) {
+#pragma unroll
+        for (int j = 1; j < 8; ++j) s += red[j * 32 + col];
+        if (i + 4 <= n) *reinterpret_cast<f32x4*>(out + i) = s;
+        else for (int e = 0; e < 4 && i + e < n; ++e) out[i + e] = s[e];
     }
 }
 
@@ -731,7 +737,7 @@ extern "C" int runet_conv_wgrad(const float* x, int ldx, const float* dy, int ld
         else if (p.tn == 2) launch_wgrad_tile<1, 1, 2>(t, p, st);
         else launch_wgrad_tile<1, 1, 1>(t, p, st);
         if (p.splits > 1)
-            hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(wsize, 256 * 4)), dim3(256), 0, st, workspace, dw, wsize, p.splits);
+            hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(wsize, 32 * 4)), dim3(256), 0, st, workspace, dw, wsize, p.splits);
         RUNET_CHECK_LAUNCH();
     }
     WGradArgs a{};
@@ -768,7 +774,7 @@ extern "C" int runet_conv_wgrad(const float* x, int ldx, const float* dy, int ld
     }
     if (splits > 1) {
         const int thr = 256;
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(wsize, thr * 4)), dim3(thr), 0, st, workspace, dw, wsize, splits);
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(wsize, 32 * 4)), dim3(256), 0, st, workspace, dw, wsize, splits);
     }
     RUNET_CHECK_LAUNCH();
 }
