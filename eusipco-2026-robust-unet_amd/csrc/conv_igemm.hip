@@ -181,51 +181,67 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IGemmArgs g) {
         if (more) load_tile();
         const float* As = smem + cur * STAGE;
         const float* Bs = As + A_ELEMS;
+        // all fragments of the k-step are read up front (2*TM ds_read_b128 + 4*TN ds_read2_b32), then the MFMA chain runs
+        // without LDS waits inside it; the scheduler is told to keep that order (it otherwise sinks each B read to its use)
+        f32x4 af[2][TM];
+        float bf[2][TN][4];
 #pragma unroll
-        for (int kb = 0; kb < 16; kb += 8) {
-            f32x4 af[TM];
-            float bf[TN][4];
+        for (int kh = 0; kh < 2; ++kh) {
 #pragma unroll
             for (int a = 0; a < TM; ++a)
-                af[a] = *reinterpret_cast<const f32x4*>(As + (wm0 + a * 32 + li) * LDA + kb + 4 * lh);
+                af[kh][a] = *reinterpret_cast<const f32x4*>(As + (wm0 + a * 32 + li) * LDA + kh * 8 + 4 * lh);
 #pragma unroll
             for (int b = 0; b < TN; ++b)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) bf[b][q] = Bs[(kb + 4 * lh + q) * LDB + wn0 + b * 32 + li];
+                for (int q = 0; q < 4; ++q) bf[kh][b][q] = Bs[(kh * 8 + 4 * lh + q) * LDB + wn0 + b * 32 + li];
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * TM + 4 * TN, 0);     // DS reads first
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
                 for (int a = 0; a < TM; ++a)
 #pragma unroll
                     for (int b = 0; b < TN; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][q], bf[b][q], acc[a][b], 0, 0, 0);
-        }
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kh][a][q], bf[kh][b][q], acc[a][b], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x8, 8 * TM * TN, 0);            // then the whole MFMA chain
         if (more) store_tile(cur ^ 1);
         __syncthreads();
         cur ^= 1;
     }
 
     // ---- epilogue: D[row = pixel][col = n]; lane holds col (lane&31), rows (r&3)+8*(r>>2)+4*(lane>>5) ----
+    const bool same_pix = (g.o_scale == 1 && g.Hout == g.H && g.Wout == g.W);   // plain conv: destination pixel == GEMM row
+    int ncol[TN];
+    float bv[TN];
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
-        const int n = n0 + wn0 + b * 32 + li;
-        const bool n_ok = n < g.Ncols;
-        const float bv = (g.bias != nullptr && n_ok) ? g.bias[n] : 0.f;
+        ncol[b] = n0 + wn0 + b * 32 + li;
+        bv[b] = (g.bias != nullptr && ncol[b] < g.Ncols) ? g.bias[ncol[b]] : 0.f;
+    }
 #pragma unroll
-        for (int a = 0; a < TM; ++a) {
+    for (int a = 0; a < TM; ++a) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const long p = m0 + wm0 + a * 32 + row;
-                if (n_ok && p < P) {
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const long p = m0 + wm0 + a * 32 + row;
+            if (p < P) {
+                long op = p;
+                if (!same_pix) {
                     const int nimg = (int)(p / HW);
                     const int rem = (int)(p - (long)nimg * HW);
                     const int h = rem / g.W, w = rem - h * g.W;
-                    const long op = ((long)nimg * g.Hout + (h * g.o_scale + o_dh)) * g.Wout + (w * g.o_scale + o_dw);
-                    float* dst = g.y + op * g.ldy + n;
-                    float v = acc[a][b][r] + bv;
-                    if (g.accumulate) v += *dst;
-                    *dst = v;
+                    op = ((long)nimg * g.Hout + (h * g.o_scale + o_dh)) * g.Wout + (w * g.o_scale + o_dw);
+                }
+                float* drow = g.y + op * g.ldy;
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    if (ncol[b] < g.Ncols) {
+                        float v = acc[a][b][r] + bv[b];
+                        if (g.accumulate) v += drow[ncol[b]];
+                        drow[ncol[b]] = v;
+                    }
                 }
             }
         }

@@ -107,3 +107,37 @@ def test_input_validation(pkg):
         model(torch.zeros((1, 3, 40, 40), device=dev))           # not a multiple of 16
     with pytest.raises(RuntimeError):
         model(torch.zeros((1, 3, 32, 32)))                       # CPU tensor: no fallback
+
+
+def test_reference_style_loop_with_stock_loss_and_optimizer(pkg):
+    """the reference's own loop (nn.BCELoss + torch.optim.Adam) runs against the drop-in module,
+    and gives the same update as the fused loss/optimizer."""
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    a = pkg.RobustUNet(3, 1, 16).to(dev)
+    b = pkg.RobustUNet(3, 1, 16).to(dev)
+    b.load_state_dict(a.state_dict())
+    x, y = pkg.synthetic_batch(2, 32, seed=11)
+    x, y = x.to(dev), y.to(dev)
+    masks = {k: torch.ones(2, rb.out_channels) for k, rb in a._rbs().items()}
+    for m in (a, b):
+        m.train()
+        m.set_dropout_masks(masks)
+    opt_a = torch.optim.Adam(a.parameters(), lr=1e-4, weight_decay=1e-4)
+    opt_a.zero_grad()
+    loss_a = torch.nn.BCELoss()(a(x), y)
+    loss_a.backward()
+    opt_a.step()
+    opt_b = pkg.FusedAdam(b.parameters(), lr=1e-4, weight_decay=1e-4)
+    opt_b.zero_grad()
+    loss_b = pkg.bce_loss(b(x), y)
+    loss_b.backward()
+    opt_b.step()
+    assert abs(loss_a.item() - loss_b.item()) < 1e-6
+    for (k, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        assert torch.allclose(pa, pb, rtol=0, atol=2e-6), k
+    # gradient accumulation: a second backward without zero_grad adds into p.grad
+    g1 = b.inc.conv2.weight.grad.clone()
+    pkg.bce_loss(b(x), y).backward()
+    g2 = b.inc.conv2.weight.grad
+    assert not torch.equal(g1, g2) and float(g2.abs().sum()) > float(g1.abs().sum())
