@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="images per GPU")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--base", type=int, default=64)
+    ap.add_argument("--sync-bn", action="store_true", help="cross-rank BatchNorm statistics (results equal the global-batch step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -115,7 +116,7 @@ def main():
     model = pkg.RobustUNet(3, 1, args.base).to(dev).train()
     sync = None
     if world > 1:
-        sync = pkg.GradAllReducer(model)
+        sync = pkg.GradAllReducer(model, sync_bn=args.sync_bn)
         sync.broadcast_parameters(0)
     step = pkg.TrainStep(model, lr=1e-4, weight_decay=1e-4, grad_sync=sync)
     x, y = pkg.synthetic_batch(args.batch, args.size, seed=1234 + rank)
@@ -159,7 +160,7 @@ def main():
             "config": {"workload": f"Robust U-Net base{args.base} (40.9M params) train step, {args.size}x{args.size} RGB+mask tiles, "
                                    f"batch {args.batch}/GPU, fp32, BCE + Adam(lr 1e-4, wd 1e-4), dropout + batch-stat BN on",
                        "global_batch": world * args.batch, "image_size": args.size,
-                       "parallelism": f"dp{world}" + (" (RCCL grad all-reduce overlapped with backward, per-rank BN)" if world > 1 else "")},
+                       "parallelism": f"dp{world}" + (f" (RCCL grad all-reduce overlapped with backward, {'SyncBN' if args.sync_bn else 'per-rank BN'})" if world > 1 else "")},
             "final_loss": round(final_loss, 5),
         }
         if roof is not None:

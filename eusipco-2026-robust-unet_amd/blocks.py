@@ -113,12 +113,11 @@ def bn_coeff(x, bn: BNState, training, sm: Small, want_minmax=False, stats_hook=
         check(lib.runet_chan_stats(x.data_ptr(), ops.ld(x), n, hw, c, ws.data_ptr(), mean_nc.data_ptr(), m2_nc.data_ptr(),
                                    nc[2].data_ptr() if nc else None, nc[3].data_ptr() if nc else None,
                                    nc[4].data_ptr() if nc else None, nc[5].data_ptr() if nc else None, int(want_minmax), st))
-        if stats_hook is not None and training:   # SyncBN: merge (mean, M2) across ranks before finalising
-            mean_nc, m2_nc, n_eff = stats_hook(mean_nc, m2_nc, n, hw, c)
-        else:
-            n_eff = n
+        mean_all, m2_all, n_eff = mean_nc, m2_nc, n
+        if stats_hook is not None and training:   # SyncBN: every rank's per-image (mean, M2) rows, Chan-combined by bn_finalize
+            mean_all, m2_all, n_eff = stats_hook.gather_stats(mean_nc, m2_nc, n, c)
     if training:
-        check(lib.runet_bn_finalize(mean_nc.data_ptr(), m2_nc.data_ptr(), n_eff, c, hw, bn.weight.data_ptr(), bn.bias.data_ptr(),
+        check(lib.runet_bn_finalize(mean_all.data_ptr(), m2_all.data_ptr(), n_eff, c, hw, bn.weight.data_ptr(), bn.bias.data_ptr(),
                                     bn.running_mean.data_ptr(), bn.running_var.data_ptr(), bn.nbt.data_ptr(), BN_MOMENTUM, BN_EPS, 1,
                                     scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), st))
     else:
@@ -137,8 +136,9 @@ def bn_apply(x, scale, shift, mask=None, relu=False, out=None):
     return out
 
 
-def bn_backward(dy, x, mean, invstd, scale, sums, act=None, mask=None, out=None):
-    """sums: [2c] destination for (dgamma | dbeta).  act/mask: fused relu(+dropout) backward.  -> dx"""
+def bn_backward(dy, x, mean, invstd, scale, sums, act=None, mask=None, out=None, sync=None):
+    """sums: [2c] destination for (dgamma | dbeta), always the LOCAL sums.  act/mask: fused relu(+dropout) backward.
+    sync (SyncBN): dx uses the all-reduced sums and the global element count.  -> dx"""
     n, h, w, c = x.shape
     hw = h * w
     st = ops.stream()
@@ -149,8 +149,9 @@ def bn_backward(dy, x, mean, invstd, scale, sums, act=None, mask=None, out=None)
                                   maskp, ws.data_ptr(), sums.data_ptr(), st))
     if out is None:
         out = ops.empty_nhwc(n, h, w, c, x)
+    use, m_total = (sums, 0) if sync is None else sync.reduce_sums(sums, n * hw)
     check(lib.runet_bn_bwd_apply(dy.data_ptr(), ops.ld(dy), x.data_ptr(), ops.ld(x), actp, lda, out.data_ptr(), ops.ld(out), n * hw, hw, c,
-                                 mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), sums.data_ptr(), maskp, st))
+                                 mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), use.data_ptr(), maskp, m_total, st))
     return out
 
 
@@ -208,7 +209,7 @@ def rb_forward(x, p: RBParams, training, mask=None, save=True, stats_hook=None):
                            ops.ld(out), P, hw, c, st))
     if not save:
         return out, None
-    ctx = dict(x=x, r=r, t1=t1, a1=a1, t2=t2, out=out, mask=use_mask, p=p, s1=s1, mean1=mean1, invstd1=invstd1, s2=s2, h2=h2,
+    ctx = dict(x=x, r=r, t1=t1, a1=a1, t2=t2, out=out, mask=use_mask, p=p, sync=stats_hook if training else None, s1=s1, mean1=mean1, invstd1=invstd1, s2=s2, h2=h2,
                mean2=mean2, invstd2=invstd2, ss=ss, mean_s=mean_s, invstd_s=invstd_s, A=A, B=B, ca=ca, avg=avg, mx=mx, idx=idx,
                tval=tval, mean_nc=mean_nc, smap=smap, amax=amax, sa=sa)
     return out, ctx
@@ -247,19 +248,21 @@ def rb_backward(ctx, dout, sink, pre="", need_dx=True):
                            ctx["tval"].data_ptr(), ctx["mean2"].data_ptr(), ctx["invstd2"].data_ptr(), n, c, cr, ws.data_ptr(),
                            davg.data_ptr(), dmx.data_ptr(), sums2.data_ptr(), dw0p.data_ptr(), dw2p.data_ptr(), st))
     dt2 = ops.empty_nhwc(n, h, w, c, x)
+    sync = ctx["sync"]
+    use2, m_total = (sums2, 0) if sync is None else sync.reduce_sums(sums2, P)
     check(lib.runet_rb_bwd3(dv.data_ptr(), ops.ld(dv), t2.data_ptr(), ops.ld(t2), sa.data_ptr(), dsm.data_ptr(), amax.data_ptr(),
                             ctx["ca"].data_ptr(), davg.data_ptr(), dmx.data_ptr(), ctx["idx"].data_ptr(), ctx["mean2"].data_ptr(),
-                            ctx["invstd2"].data_ptr(), ctx["s2"].data_ptr(), sums2.data_ptr(), dt2.data_ptr(), ops.ld(dt2), P, hw, c, st))
+                            ctx["invstd2"].data_ptr(), ctx["s2"].data_ptr(), use2.data_ptr(), dt2.data_ptr(), ops.ld(dt2), P, hw, c, m_total, st))
     ops.conv_wgrad(a1, dt2, 3, 3, out=sink.buf(pre, [("conv2.weight", (3, 3, c, c))]))
     da1 = ops.conv_dgrad(dt2, p.w2)
     del dt2
     sums1 = sink.buf(pre, [("bn1.weight", (c,)), ("bn1.bias", (c,))])
-    dt1 = bn_backward(da1, t1, ctx["mean1"], ctx["invstd1"], ctx["s1"], sums1, act=a1, mask=ctx["mask"], out=da1)
+    dt1 = bn_backward(da1, t1, ctx["mean1"], ctx["invstd1"], ctx["s1"], sums1, act=a1, mask=ctx["mask"], out=da1, sync=sync)
     ops.conv_wgrad(x, dt1, 3, 3, cin_w=p.cin_w, out=sink.buf(pre, [("conv1.weight", (3, 3, p.cin_w, c))]))
     dx = None
     if p.ws is not None:
         sums_s = sink.buf(pre, [("shortcut.1.weight", (c,)), ("shortcut.1.bias", (c,))])
-        dr = bn_backward(dv, r, ctx["mean_s"], ctx["invstd_s"], ctx["ss"], sums_s, out=dv)
+        dr = bn_backward(dv, r, ctx["mean_s"], ctx["invstd_s"], ctx["ss"], sums_s, out=dv, sync=sync)
         ops.conv_wgrad(x, dr, 1, 1, cin_w=p.cin_w, out=sink.buf(pre, [("shortcut.0.weight", (1, 1, p.cin_w, c))]))
         if need_dx:
             dx = ops.conv_dgrad(dt1, p.w1)
@@ -292,7 +295,7 @@ def dilated_forward(x, p: DilParams, training, save=True, stats_hook=None):
     out = bn_apply(cat, s, hsh, None, relu=True)
     if not save:
         return out, None
-    return out, dict(x=x, cat=cat, out=out, p=p, s=s, mean=mean, invstd=invstd)
+    return out, dict(x=x, cat=cat, out=out, p=p, s=s, mean=mean, invstd=invstd, sync=stats_hook if training else None)
 
 
 def dilated_backward(ctx, dout, sink, pre="", need_dx=True):
@@ -305,7 +308,7 @@ def dilated_backward(ctx, dout, sink, pre="", need_dx=True):
     wb = [sink.buf(pre, [(f"conv{i + 1}.weight", (1 if i == 0 else 3, 1 if i == 0 else 3, cin, q)), (f"conv{i + 1}.bias", (q,))])
           for i in range(4)]
     sums = sink.buf(pre, [("bn.weight", (c,)), ("bn.bias", (c,))])
-    dcat = bn_backward(dout, cat, ctx["mean"], ctx["invstd"], ctx["s"], sums, act=out, mask=None)
+    dcat = bn_backward(dout, cat, ctx["mean"], ctx["invstd"], ctx["s"], sums, act=out, mask=None, sync=ctx["sync"])
     dx = None
     for i in range(4):
         sl = dcat[..., i * q:(i + 1) * q]
@@ -342,7 +345,7 @@ def gate_forward(up, skip, p: UpGateParams, training, att_out, sm, stats_hook=No
                            p.wpsi.data_ptr(), p.bpsi.data_ptr(), s.data_ptr(), P, f, st))
     sp, hp, mean_p, invstd_p, _ = bn_coeff(s, p.bnp, training, sm, stats_hook=stats_hook)
     check(lib.runet_ag_out(skip.data_ptr(), ops.ld(skip), s.data_ptr(), sp.data_ptr(), hp.data_ptr(), att_out.data_ptr(), ops.ld(att_out), P, c, st))
-    return dict(g1=g1, x1=x1, s=s, sg=sg, hg=hg, mean_g=mean_g, invstd_g=invstd_g, sx=sx, hx=hx, mean_x=mean_x, invstd_x=invstd_x,
+    return dict(sync=stats_hook if training else None, g1=g1, x1=x1, s=s, sg=sg, hg=hg, mean_g=mean_g, invstd_g=invstd_g, sx=sx, hx=hx, mean_x=mean_x, invstd_x=invstd_x,
                 sp=sp, hp=hp, mean_p=mean_p, invstd_p=invstd_p)
 
 
@@ -365,18 +368,19 @@ def gate_backward(gc, up, skip, p: UpGateParams, datt, dup, sink, pre=""):
     dsbn = torch.empty((n, h, w, 1), device=dev, dtype=torch.float32)
     check(lib.runet_ag_bwd1(datt.data_ptr(), ops.ld(datt), skip.data_ptr(), ops.ld(skip), gc["s"].data_ptr(), gc["sp"].data_ptr(),
                             gc["hp"].data_ptr(), dskip.data_ptr(), ops.ld(dskip), dsbn.data_ptr(), P, c, st))
-    ds = bn_backward(dsbn, gc["s"], gc["mean_p"], gc["invstd_p"], gc["sp"], sums_p, out=dsbn)
+    sync = gc["sync"]
+    ds = bn_backward(dsbn, gc["s"], gc["mean_p"], gc["invstd_p"], gc["sp"], sums_p, out=dsbn, sync=sync)
     dpre = ops.empty_nhwc(n, h, w, f, skip)
     ws = _ws(n, h * w, f, dev)
     check(lib.runet_ag_bwd2(ds.data_ptr(), gc["g1"].data_ptr(), ops.ld(gc["g1"]), gc["x1"].data_ptr(), ops.ld(gc["x1"]), gc["sg"].data_ptr(),
                             gc["hg"].data_ptr(), gc["sx"].data_ptr(), gc["hx"].data_ptr(), p.wpsi.data_ptr(), dpre.data_ptr(), ops.ld(dpre),
                             ws.data_ptr(), dwpsi_db.data_ptr(), P, f, st))
-    dg1 = bn_backward(dpre, gc["g1"], gc["mean_g"], gc["invstd_g"], gc["sg"], sums_g)
+    dg1 = bn_backward(dpre, gc["g1"], gc["mean_g"], gc["invstd_g"], gc["sg"], sums_g, sync=sync)
     ops.conv_wgrad(up, dg1, 1, 1, out=wg_b[:cg * f])
     chan_sum(dg1, wg_b[cg * f:])
     ops.conv_dgrad(dg1, p.wg, out=dup, accumulate=True)
     del dg1
-    dx1 = bn_backward(dpre, gc["x1"], gc["mean_x"], gc["invstd_x"], gc["sx"], sums_x, out=dpre)
+    dx1 = bn_backward(dpre, gc["x1"], gc["mean_x"], gc["invstd_x"], gc["sx"], sums_x, out=dpre, sync=sync)
     ops.conv_wgrad(skip, dx1, 1, 1, out=wx_b[:c * f])
     chan_sum(dx1, wx_b[c * f:])
     ops.conv_dgrad(dx1, p.wx, out=dskip, accumulate=True)

@@ -691,11 +691,11 @@ extern "C" int runet_ca_bwd(const float* sdu, const float* sdut, const float* s2
 extern "C" int runet_rb_bwd3(const float* dv, int lddv, const float* t2, int ld, const float* sa, const float* dsm, const int* amax,
                              const float* ca, const float* davg, const float* dmx, const int* idx, const float* mean2,
                              const float* invstd2, const float* s2, const float* sums2, float* dt2, int lddt, long pixels, int hw, int c,
-                             void* stream) {
+                             long m_total, void* stream) {
     RUNET_REQUIRE(dv && t2 && sa && dsm && amax && ca && davg && dmx && idx && mean2 && invstd2 && s2 && sums2 && dt2, "null pointer");
     REQ_C4(c);
     hipLaunchKernelGGL(rb_bwd3_kernel, dim3(ew_grid(pixels * (c / 4))), dim3(TPB), 0, (hipStream_t)stream, dv, lddv, t2, ld, sa, dsm, amax, ca, davg,
-                       dmx, idx, mean2, invstd2, s2, sums2, dt2, lddt, pixels, hw, c, 1.0f / (float)pixels);
+                       dmx, idx, mean2, invstd2, s2, sums2, dt2, lddt, pixels, hw, c, 1.0f / (float)(m_total > 0 ? m_total : pixels));
     RUNET_CHECK_LAUNCH();
 }
 

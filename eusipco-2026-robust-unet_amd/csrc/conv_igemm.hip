@@ -129,11 +129,12 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IGemmArgs g) {
                 rb[i] = v;
             }
         }
-        // advance counters: kc fastest, then tap column, then tap row
-        if (++ld_kc == KC) {
-            ld_kc = 0;
-            ++ld_tap;
-            if (++ld_ts == g.KW) { ld_ts = 0; ++ld_tr; }
+        // advance counters: tap fastest (column, then row), then the channel chunk - the 9 shifted reads of one 16-channel
+        // chunk touch the same cache lines back to back, so 8 of them are served by L1/L2 instead of the fabric
+        ++ld_tap;
+        if (++ld_ts == g.KW) {
+            ld_ts = 0;
+            if (++ld_tr == g.KH) { ld_tr = 0; ld_tap = 0; ++ld_kc; }
         }
     };
 

@@ -463,11 +463,11 @@ extern "C" int runet_bn_bwd_reduce(const float* dy, int lddy, const float* x, in
 
 extern "C" int runet_bn_bwd_apply(const float* dy, int lddy, const float* x, int ldx, const float* act, int ldact, float* dx,
                                   int lddx, long pixels, int hw, int c, const float* mean, const float* invstd,
-                                  const float* scale, const float* sums, const float* mask_nc, void* stream) {
+                                  const float* scale, const float* sums, const float* mask_nc, long m_total, void* stream) {
     RUNET_REQUIRE(dy && x && dx && mean && invstd && scale && sums, "null pointer");
     REQ_VEC(c);
     hipStream_t st = (hipStream_t)stream;
-    const float inv_m = 1.0f / (float)pixels;
+    const float inv_m = 1.0f / (float)(m_total > 0 ? m_total : pixels);
     if (c % 4 == 0) hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3(ew_grid(pixels * (c / 4))), dim3(TPB), 0, st, dy, lddy, x, ldx, act, ldact, dx, lddx, pixels, hw, c, mean, invstd, scale, sums, mask_nc, inv_m);
     else hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3(ew_grid(pixels * c)), dim3(TPB), 0, st, dy, lddy, x, ldx, act, ldact, dx, lddx, pixels, hw, c, mean, invstd, scale, sums, mask_nc, inv_m);
     RUNET_CHECK_LAUNCH();

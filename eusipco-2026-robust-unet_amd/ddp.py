@@ -14,7 +14,8 @@ north_star asks for.  Design for MI355X:
 * `finish()` makes the compute stream wait for the communication stream before the optimizer step; the
   1/world_size averaging is folded into the fused Adam kernel (`FusedAdam.grad_scale`).
 
-BatchNorm uses per-rank batch statistics (what torch's DistributedDataParallel does by default).
+BatchNorm uses per-rank batch statistics by default (what torch's DistributedDataParallel does); `sync_bn=True`
+installs `SyncBatchNorm`, which makes the N-rank step equal to the single-process step on the concatenated batch.
 """
 from __future__ import annotations
 
@@ -23,7 +24,7 @@ import torch.distributed as dist
 
 
 class GradAllReducer:
-    def __init__(self, model, bucket_floats=8 << 20, process_group=None, average_in_optimizer=True):
+    def __init__(self, model, bucket_floats=8 << 20, process_group=None, average_in_optimizer=True, sync_bn=False):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.model = model
@@ -36,6 +37,8 @@ class GradAllReducer:
         self._sent = 0
         self._work = []
         self.buckets_last_step = []
+        if sync_bn:
+            model.sync_bn_hook = SyncBatchNorm(process_group)
 
     # -- wiring ------------------------------------------------------------------------------
     def attach(self, optimizer=None):
@@ -93,6 +96,32 @@ class GradAllReducer:
             self._work = []
             if not self.average_in_optimizer:
                 self.arena.flat.mul_(1.0 / self.world)
+
+
+class SyncBatchNorm:
+    """Cross-rank batch statistics for every BatchNorm of the path (per-rank BN at 2 images/GPU is a
+    different function from the reference's global-batch BN).  Forward: the per-image (mean, M2) rows of all ranks are
+    all-gathered and Chan-combined by `runet_bn_finalize` exactly as a single process would combine its own images.
+    Backward: the two per-channel sums that enter dx are all-reduced (the parameter gradients stay local sums and are
+    averaged with everything else by the gradient all-reduce).  Messages are [2*N*C] / [2*C] floats: latency-bound."""
+
+    def __init__(self, process_group=None):
+        self.group = process_group
+        self.world = dist.get_world_size(process_group)
+
+    def gather_stats(self, mean_nc, m2_nc, n, c):
+        local = torch.cat([mean_nc.reshape(-1), m2_nc.reshape(-1)])
+        parts = [torch.empty_like(local) for _ in range(self.world)]
+        dist.all_gather(parts, local, group=self.group)
+        k = n * c
+        mean_all = torch.cat([p[:k] for p in parts])
+        m2_all = torch.cat([p[k:] for p in parts])
+        return mean_all, m2_all, n * self.world
+
+    def reduce_sums(self, sums, local_count):
+        g = sums.clone()
+        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+        return g, local_count * self.world
 
 
 def _dense(t):

@@ -78,10 +78,10 @@ int runet_bn_apply(const float* x, int ldx, float* y, int ldy, long pixels, int 
  * sums[0:c] = sum g*xhat (= dgamma), sums[c:2c] = sum g (= dbeta): the order of (weight, bias). */
 int runet_bn_bwd_reduce(const float* dy, int lddy, const float* x, int ldx, const float* act, int ldact, int n_img, int hw, int c,
                         const float* mean, const float* invstd, const float* mask_nc, float* workspace, float* sums, void* stream);
-/* dx = scale*(g - sums[C+c]/M - xhat*sums[c]/M), M = pixels */
+/* dx = scale*(g - sums[C+c]/M - xhat*sums[c]/M), M = m_total if > 0 else pixels (SyncBN: sums all-reduced, M = global count) */
 int runet_bn_bwd_apply(const float* dy, int lddy, const float* x, int ldx, const float* act, int ldact, float* dx, int lddx,
                        long pixels, int hw, int c, const float* mean, const float* invstd, const float* scale, const float* sums,
-                       const float* mask_nc, void* stream);
+                       const float* mask_nc, long m_total, void* stream);
 /* out[c] (=|+=) sum over pixels of x[p, c]  (bias gradients) */
 int runet_chan_sum(const float* x, int ld, long pixels, int c, float* workspace, float* out, int accumulate, void* stream);
 
@@ -109,7 +109,7 @@ int runet_ca_bwd(const float* sdu, const float* sdut, const float* s2, const flo
                  int n_img, int c, int cr, float* workspace, float* davg, float* dmx, float* sums2, float* dw0p, float* dw2p, void* stream);
 int runet_rb_bwd3(const float* dv, int lddv, const float* t2, int ld, const float* sa, const float* dsm, const int* amax, const float* ca,
                   const float* davg, const float* dmx, const int* idx, const float* mean2, const float* invstd2, const float* s2,
-                  const float* sums2, float* dt2, int lddt, long pixels, int hw, int c, void* stream);
+                  const float* sums2, float* dt2, int lddt, long pixels, int hw, int c, long m_total, void* stream);
 
 /* ---- AttentionGate (Main_Final.py:120-148): psi conv (F_int -> 1) and the gating multiply ---- */
 int runet_ag_psi(const float* g1, int ldg, const float* x1, int ldx, const float* sg, const float* hg, const float* sx, const float* hx,
