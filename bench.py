@@ -164,8 +164,14 @@ def main():
             "final_loss": round(final_loss, 5),
         }
         if roof is not None:
+            traffic = None
+            try:   # HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 cannot run inside bench.py)
+                with open(os.path.join(ROOT, "profiles", "round1_pmc_traffic.json")) as f:
+                    traffic = json.load(f)["kernels"].get(roof["kernel"], {}).get("hbm_bytes_per_launch_corrected")
+            except (OSError, ValueError, KeyError):
+                pass
             out["roofline"] = {"bound": "mfma", "achieved": round(roof["tflops"], 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(roof["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                               "frac": round(roof["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                                "kernel": roof["kernel"], "launches_per_step": roof["launches"] // args.steps,
                                "avg_launch_us": round(roof["avg_us"], 2), "share_of_step": round(roof["time_s"] / dt, 3),
                                "by_kernel": roof["by_kernel"]}
