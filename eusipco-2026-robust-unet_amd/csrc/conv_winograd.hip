@@ -1,0 +1,283 @@
+// Fused Winograd F(2x2, 3x3) convolution on the fp32 matrix cores: forward and data-gradient of the 3x3 / dilation-1 /
+// 'same' convolutions of the ResidualBlocks (/root/reference/Main_Final.py:157,159 and their autograd), which are 89 % of
+// the network's FLOPs.  2.25x fewer multiplies than the direct implicit GEMM at fp32 accuracy (rounding differs by a few ulp).
+//
+//   Y = A^T [ (G g G^T) .* (B^T d B) ] A      per 2x2 output tile, 4x4 input patch d, 3x3 filter g
+//
+// * `wino_weight_kernel` transforms the HWIO weight once per use into U[16][K][N] (forward: K = cin, N = cout; data
+//   gradient: the 180-degree rotated filter with K = cout, N = cin).
+// * `wino_conv_kernel`: one block = 32 tiles (one 32-row MFMA tile) x 64 output channels.  Per 16-channel chunk every thread
+//   loads the 4x4 patch of one (tile, channel pair) straight from NHWC global memory (8 lanes cover the 64 contiguous bytes
+//   of a pixel), applies B^T d B in registers and writes the 16 transformed values to LDS as V[xi][tile][k]; after a barrier
+//   wave w multiplies positions xi = 4w..4w+3 : [32 tiles x 16 k] x [16 k x 64 n] with v_mfma_f32_32x32x2_f32, the U
+//   fragments coming straight from global/L2 (each wave needs different positions, so LDS staging would buy no reuse).
+//   The 16 position-products of an output tile live in four waves; the epilogue exchanges them through LDS in four
+//   16-channel passes, applies A^T m A, adds the bias (or accumulates) and stores the 2x2 outputs.
+// Algorithmic FLOPs are counted as the direct convolution's (2*9*Cin*Cout per pixel); the MFMA work is 16/36 of that.
+#include "runet_common.h"
+#include "../../include/runet_hip.h"
+
+namespace {
+
+struct WinoArgs {
+    const float* x; int ldx;      // [Nimg, H, W, ldx], K channels
+    const float* U;               // [16][K][N]
+    const float* bias;            // [N] or nullptr
+    float* y; int ldy;            // [Nimg, H, W, ldy], N channels
+    int K, N;
+    int Nimg, H, W, TY, TX;       // TY = H/2, TX = W/2
+    long tiles;                   // Nimg*TY*TX
+    int accumulate;
+};
+
+constexpr int WT = 32;            // tiles per block
+constexpr int WBN = 64;           // output channels per block
+constexpr int VLD = 20;           // padded k-stride of a V row (conflict-free ds_read_b128)
+
+__global__ __launch_bounds__(256, 2) void wino_conv_kernel(WinoArgs g) {
+    __shared__ __attribute__((aligned(16))) float V[16 * WT * VLD];     // 40 KB; reused as M[16][32][16] in the epilogue
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform: U pointers stay in SGPRs
+    const int li = lane & 31, lh = lane >> 5;
+    const long t0 = (long)blockIdx.x * WT;
+    const int n0 = blockIdx.y * WBN;
+
+    // ---- loader role: (tile lt, channel pair k2) ----
+    const int lt = tid >> 3, k2 = tid & 7;
+    const long tg = t0 + lt;
+    unsigned vmask = 0;           // bit (a*4+b): patch pixel in bounds
+    int pbase = 0;                // element offset of patch pixel (0,0) (may be out of bounds; only masked pixels are read)
+    {
+        const bool tv = tg < g.tiles;
+        const long tt = tv ? tg : 0;
+        const int per = g.TY * g.TX;
+        const int n = (int)(tt / per);
+        const int rem = (int)(tt - (long)n * per);
+        const int ty = rem / g.TX, tx = rem - ty * g.TX;
+        const int h0 = 2 * ty - 1, w0 = 2 * tx - 1;
+        pbase = (int)((((long)n * g.H + h0) * g.W + w0) * g.ldx + 2 * k2);
+        if (tv) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    if ((unsigned)(h0 + a) < (unsigned)g.H && (unsigned)(w0 + b) < (unsigned)g.W) vmask |= 1u << (a * 4 + b);
+        }
+    }
+    const int rowstride = g.W * g.ldx;
+
+    float2 raw[16];
+    auto load_patch = [&](int c0) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                float2 v = make_float2(0.f, 0.f);
+                const float* xb = g.x + (a * rowstride + b * g.ldx + c0);          // wave-uniform part
+                if (vmask & (1u << (a * 4 + b))) v = *reinterpret_cast<const float2*>(xb + pbase);
+                raw[a * 4 + b] = v;
+            }
+    };
+    auto transform_store = [&]() {
+        // B^T d B on both channels; V[xi][lt][2*k2 .. 2*k2+1]
+        float2 tmp[16];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const float2 d0 = raw[b], d1 = raw[4 + b], d2 = raw[8 + b], d3 = raw[12 + b];
+            tmp[b] = make_float2(d0.x - d2.x, d0.y - d2.y);
+            tmp[4 + b] = make_float2(d1.x + d2.x, d1.y + d2.y);
+            tmp[8 + b] = make_float2(d2.x - d1.x, d2.y - d1.y);
+            tmp[12 + b] = make_float2(d1.x - d3.x, d1.y - d3.y);
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const float2 v0 = tmp[a * 4], v1 = tmp[a * 4 + 1], v2 = tmp[a * 4 + 2], v3 = tmp[a * 4 + 3];
+            float2 o[4];
+            o[0] = make_float2(v0.x - v2.x, v0.y - v2.y);
+            o[1] = make_float2(v1.x + v2.x, v1.y + v2.y);
+            o[2] = make_float2(v2.x - v1.x, v2.y - v1.y);
+            o[3] = make_float2(v1.x - v3.x, v1.y - v3.y);
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                *reinterpret_cast<float2*>(&V[((a * 4 + b) * WT + lt) * VLD + 2 * k2]) = o[b];
+        }
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][b][r] = 0.f;
+
+    const int nchunks = g.K >> 4;
+    load_patch(0);
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int c0 = ch * 16;
+        __syncthreads();                       // previous chunk's MFMA reads of V are done
+        transform_store();
+        __syncthreads();
+        if (ch + 1 < nchunks) load_patch(c0 + 16);     // in flight during the MFMAs
+        // U fragments: double-buffered in registers, the next position's 16 loads are issued before this position's 16 MFMAs
+        // (sched_barrier keeps the compiler from hoisting all 64 loads to the top, which spills)
+        float bfa[2][2][4], bfb[2][2][4];
+        auto load_u = [&](int xl, float (&bf)[2][2][4]) {
+            const float* Ub = g.U + ((long)(wid * 4 + xl) * g.K + c0) * g.N + n0;      // wave-uniform
+            const int uoff = 4 * lh * g.N + li;                                        // per-lane
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        const float* up = Ub + ((kh * 8 + q) * g.N + b * 32);
+                        bf[kh][b][q] = (n0 + b * 32 + li < g.N) ? up[uoff] : 0.f;
+                    }
+        };
+        auto mma = [&](int xl, const float (&bf)[2][2][4]) {
+            const int xi = wid * 4 + xl;
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(&V[(xi * WT + li) * VLD + 4 * lh]);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(&V[(xi * WT + li) * VLD + 8 + 4 * lh]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[xl][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q], bf[0][b][q], acc[xl][b], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[xl][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q], bf[1][b][q], acc[xl][b], 0, 0, 0);
+        };
+        load_u(0, bfa);
+        __builtin_amdgcn_sched_barrier(0);
+        load_u(1, bfb);
+        mma(0, bfa);
+        __builtin_amdgcn_sched_barrier(0);
+        load_u(2, bfa);
+        mma(1, bfb);
+        __builtin_amdgcn_sched_barrier(0);
+        load_u(3, bfb);
+        mma(2, bfa);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(3, bfb);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- epilogue: exchange the 16 positions through LDS (16 output channels per pass), A^T m A, store ----
+    float* M = V;                               // M[xi][t][16]
+    const int et = tid >> 3;                    // tile of the two (tile, channel) items this thread finishes
+    const int en = (tid & 7) * 2;               // channels en, en+1 of the pass
+    const long etg = t0 + et;
+    int e_n = 0, e_h = 0, e_w = 0;
+    const bool e_ok = etg < g.tiles;
+    if (e_ok) {
+        const int per = g.TY * g.TX;
+        e_n = (int)(etg / per);
+        const int rem = (int)(etg - (long)e_n * per);
+        const int ty = rem / g.TX;
+        e_h = 2 * ty; e_w = 2 * (rem - ty * g.TX);
+    }
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        __syncthreads();
+        const int b = pass >> 1;                // which 32-wide N tile
+        if ((li >> 4) == (pass & 1)) {          // lanes whose column falls into this 16-channel pass
+#pragma unroll
+            for (int xl = 0; xl < 4; ++xl)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int t = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    M[((wid * 4 + xl) * WT + t) * 16 + (li & 15)] = acc[xl][b][r];
+                }
+        }
+        __syncthreads();
+        if (e_ok) {
+            float2 m[16];
+#pragma unroll
+            for (int xi = 0; xi < 16; ++xi) m[xi] = *reinterpret_cast<const float2*>(&M[(xi * WT + et) * 16 + en]);
+            // A^T m A : rows [1,1,1,0],[0,1,-1,-1]
+            float2 s[2][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s[0][j] = make_float2(m[j].x + m[4 + j].x + m[8 + j].x, m[j].y + m[4 + j].y + m[8 + j].y);
+                s[1][j] = make_float2(m[4 + j].x - m[8 + j].x - m[12 + j].x, m[4 + j].y - m[8 + j].y - m[12 + j].y);
+            }
+            const int nch = n0 + pass * 16 + en;
+            if (nch < g.N) {
+                float2 bv = make_float2(0.f, 0.f);
+                if (g.bias) bv = *reinterpret_cast<const float2*>(g.bias + nch);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    float2 o0 = make_float2(s[i][0].x + s[i][1].x + s[i][2].x + bv.x, s[i][0].y + s[i][1].y + s[i][2].y + bv.y);
+                    float2 o1 = make_float2(s[i][1].x - s[i][2].x - s[i][3].x + bv.x, s[i][1].y - s[i][2].y - s[i][3].y + bv.y);
+                    float* d0 = g.y + (((long)e_n * g.H + e_h + i) * g.W + e_w) * g.ldy + nch;
+                    float* d1 = d0 + g.ldy;
+                    if (g.accumulate) {
+                        const float2 p0 = *reinterpret_cast<const float2*>(d0), p1 = *reinterpret_cast<const float2*>(d1);
+                        o0.x += p0.x; o0.y += p0.y; o1.x += p1.x; o1.y += p1.y;
+                    }
+                    *reinterpret_cast<float2*>(d0) = o0;
+                    *reinterpret_cast<float2*>(d1) = o1;
+                }
+            }
+        }
+    }
+}
+
+// U[xi][k][n] = (G g G^T)[xi] ;  forward: g[r][s] = w[r][s][k][n] ;  dgrad: g[r][s] = w[2-r][2-s][n][k]  (w is [3][3][cin][cout])
+__global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int cin, int cout, int dgrad) {
+    const long total = (long)cin * cout;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int ci = (int)(i / cout), co = (int)(i - (long)ci * cout);
+    float gm[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) gm[r][s] = dgrad ? w[((long)((2 - r) * 3 + (2 - s)) * cin + ci) * cout + co] : w[((long)(r * 3 + s) * cin + ci) * cout + co];
+    float t[4][3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        t[0][s] = gm[0][s];
+        t[1][s] = 0.5f * (gm[0][s] + gm[1][s] + gm[2][s]);
+        t[2][s] = 0.5f * (gm[0][s] - gm[1][s] + gm[2][s]);
+        t[3][s] = gm[2][s];
+    }
+    const int K = dgrad ? cout : cin, N = dgrad ? cin : cout;
+    const long kn = dgrad ? ((long)co * N + ci) : ((long)ci * N + co);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const float u0 = t[a][0], u1 = 0.5f * (t[a][0] + t[a][1] + t[a][2]), u2 = 0.5f * (t[a][0] - t[a][1] + t[a][2]), u3 = t[a][2];
+        U[(long)(a * 4 + 0) * K * N + kn] = u0;
+        U[(long)(a * 4 + 1) * K * N + kn] = u1;
+        U[(long)(a * 4 + 2) * K * N + kn] = u2;
+        U[(long)(a * 4 + 3) * K * N + kn] = u3;
+    }
+}
+
+}  // namespace
+
+extern "C" int runet_wino_supported(int h, int w, int cin, int cout) {
+    return (h % 2 == 0 && w % 2 == 0 && cin % 16 == 0 && cin >= 16 && cout % 2 == 0) ? 1 : 0;
+}
+
+extern "C" int runet_wino_weights(const float* w_hwio, float* U, int cin, int cout, int dgrad, void* stream) {
+    RUNET_REQUIRE(w_hwio && U && cin > 0 && cout > 0, "bad arguments");
+    const long total = (long)cin * cout;
+    hipLaunchKernelGGL(wino_weight_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w_hwio, U, cin, cout, dgrad);
+    RUNET_CHECK_LAUNCH();
+}
+
+extern "C" int runet_wino_conv(const float* x, int ldx, const float* U, const float* bias, float* y, int ldy, int n_img, int h, int w,
+                               int k, int n, int accumulate, void* stream) {
+    RUNET_REQUIRE(x && U && y, "null pointer");
+    RUNET_REQUIRE(runet_wino_supported(h, w, k, n), "shape not supported by the Winograd kernel (H, W even; K multiple of 16; N even)");
+    RUNET_REQUIRE(ldx >= k && ldx % 2 == 0 && ldy >= n && ldy % 2 == 0, "pixel strides must be even and cover the channels");
+    RUNET_REQUIRE(((uintptr_t)x % 8) == 0 && ((uintptr_t)y % 8) == 0 && ((uintptr_t)U % 4) == 0 && (!bias || ((uintptr_t)bias % 8) == 0), "alignment");
+    WinoArgs a{};
+    a.x = x; a.ldx = ldx; a.U = U; a.bias = bias; a.y = y; a.ldy = ldy; a.K = k; a.N = n;
+    a.Nimg = n_img; a.H = h; a.W = w; a.TY = h / 2; a.TX = w / 2; a.tiles = (long)n_img * a.TY * a.TX; a.accumulate = accumulate;
+    dim3 grid(cdiv(a.tiles, WT), cdiv(n, WBN));
+    hipLaunchKernelGGL(wino_conv_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    RUNET_CHECK_LAUNCH();
+}

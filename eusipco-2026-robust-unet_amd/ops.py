@@ -6,6 +6,8 @@ channel slice of a wider concat buffer).  All launches go to torch's current HIP
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from ._lib import check, lib
@@ -94,9 +96,18 @@ def _igemm(mode, x, ldx, w, bias, y, ldy, n, h, wd, cin, cin_w, cout, kh, kw, di
     _PROFILE.append((name, 2.0 * n * h * wd * taps * min(cin, cin_w) * cout, e0, e1))
 
 
+USE_WINOGRAD = os.environ.get("RUNET_NO_WINOGRAD", "0") != "1"
+
+
+def _wino_case(h, w, kh, dil, k, n, cin_w):
+    return USE_WINOGRAD and kh == 3 and dil == 1 and cin_w == k and bool(lib.runet_wino_supported(h, w, k, n))
+
+
 def conv_fwd(x, w_hwio, bias=None, out=None, dil=1, accumulate=False):
     n, h, w, cin = x.shape
     kh, kw, cin_w, cout = w_hwio.shape
+    if _wino_case(h, w, kh, dil, cin, cout, cin_w):
+        return wino_conv(x, wino_weights(w_hwio), bias, out=out, accumulate=accumulate)
     if out is None:
         out = empty_nhwc(n, h, w, cout, x)
     _igemm(CONV_FWD, x.data_ptr(), ld(x), w_hwio.data_ptr(), bias.data_ptr() if bias is not None else None,
@@ -104,10 +115,42 @@ def conv_fwd(x, w_hwio, bias=None, out=None, dil=1, accumulate=False):
     return out
 
 
+def wino_weights(w_hwio, dgrad=False):
+    """HWIO 3x3 weight -> Winograd-domain U[16][K][N] (forward: K=cin, N=cout; dgrad: rotated filter, K=cout, N=cin)."""
+    _, _, cin, cout = w_hwio.shape
+    k, n = (cout, cin) if dgrad else (cin, cout)
+    U = torch.empty((16, k, n), device=w_hwio.device, dtype=torch.float32)
+    check(lib.runet_wino_weights(w_hwio.data_ptr(), U.data_ptr(), cin, cout, int(dgrad), stream()))
+    return U
+
+
+def wino_conv(x, U, bias=None, out=None, accumulate=False):
+    """3x3 'same' convolution (or its data gradient, with dgrad weights) through the fused Winograd kernel."""
+    n, h, w, k = x.shape
+    nn_ = U.shape[2]
+    if out is None:
+        out = empty_nhwc(n, h, w, nn_, x)
+    if _PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(lib.runet_wino_conv(x.data_ptr(), ld(x), U.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(), ld(out),
+                              n, h, w, k, nn_, int(accumulate), stream()))
+    if _PROFILE is not None:
+        e1.record()
+        _PROFILE.append(("wino_conv_kernel", 2.0 * n * h * w * 9 * k * nn_, e0, e1))
+    return out
+
+
+def wino_ok(h, w, cin, cout):
+    return bool(lib.runet_wino_supported(h, w, cin, cout))
+
+
 def conv_dgrad(dy, w_hwio, out=None, dil=1, accumulate=False):
     n, h, w, cout = dy.shape
     kh, kw, cin, cout_w = w_hwio.shape
     assert cout_w == cout
+    if _wino_case(h, w, kh, dil, cout, cin, cout):
+        return wino_conv(dy, wino_weights(w_hwio, dgrad=True), None, out=out, accumulate=accumulate)
     if out is None:
         out = empty_nhwc(n, h, w, cin, dy)
     _igemm(CONV_DGRAD, dy.data_ptr(), ld(dy), w_hwio.data_ptr(), None, out.data_ptr(), ld(out), n, h, w,

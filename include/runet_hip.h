@@ -54,6 +54,15 @@ int runet_conv_wgrad(const float* x, int ldx, const float* dy, int ldy, float* d
                      int kh, int kw, int dil, int transposed, void* stream);
 
 
+/* ---- Winograd F(2x2,3x3) path for the 3x3 / dilation-1 / 'same' convolutions (Main_Final.py:157,159), forward and data gradient ----
+ * runet_wino_weights: U[16][K][N] = G g G^T of w[3][3][cin][cout]; dgrad = 0: K = cin, N = cout;  dgrad != 0: the 180-degree rotated
+ * filter with K = cout, N = cin (so that runet_wino_conv(dy, U') is the data gradient).
+ * runet_wino_conv: y[n,h,w,0:N] (=|+=) bias + winograd_conv(x[n,h,w,0:K], U).  Needs H, W even, K % 16 == 0, N even. */
+int runet_wino_supported(int h, int w, int cin, int cout);
+int runet_wino_weights(const float* w_hwio, float* U, int cin, int cout, int dgrad, void* stream);
+int runet_wino_conv(const float* x, int ldx, const float* U, const float* bias, float* y, int ldy, int n_img, int h, int w, int k, int n,
+                    int accumulate, void* stream);
+
 /* ---- channel statistics / BatchNorm2d / ReLU / Dropout2d (Main_Final.py:158,160,162,163,173,127,132,137,210,211) ----
  * Scratch buffers ("workspace") are caller-owned; runet_reduce_workspace_floats gives a sufficient size. */
 long runet_reduce_workspace_floats(int n_img, int hw, int c);

@@ -43,9 +43,11 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("wino", [False, True])
 @pytest.mark.parametrize("n,h,w,cin,cout,k,dil", CASES)
-def test_conv_fwd_dgrad_wgrad(n, h, w, cin, cout, k, dil):
+def test_conv_fwd_dgrad_wgrad(n, h, w, cin, cout, k, dil, wino, monkeypatch):
     ops = _ops()
+    monkeypatch.setattr(ops, "USE_WINOGRAD", wino)      # direct implicit GEMM and (where the shape allows) Winograd
     dev = torch.device("cuda:0")
     x = rnd((n, cin, h, w), 1)
     wt = rnd((cout, cin, k, k), 2, std=(2.0 / (cin * k * k)) ** 0.5)
@@ -122,3 +124,28 @@ def test_conv_rejects_bad_shapes():
     w = torch.zeros((3, 3, 6, 16), device=dev)
     with pytest.raises(RuntimeError):
         ops.conv_fwd(x, w)
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout", [(2, 8, 8, 16, 32), (1, 12, 20, 64, 128), (3, 4, 4, 128, 256), (2, 16, 16, 32, 48),
+                                            (2, 64, 64, 64, 64), (1, 32, 32, 256, 64), (5, 6, 10, 48, 32)])
+def test_winograd_fwd_and_dgrad(n, h, w, cin, cout):
+    """Fused Winograd F(2x2,3x3) kernel vs torch CPU conv (forward with bias, data gradient with accumulate into a slice)."""
+    ops = _ops()
+    dev = torch.device("cuda:0")
+    x = rnd((n, cin, h, w), 21)
+    wt = rnd((cout, cin, 3, 3), 22, std=(2.0 / (cin * 9)) ** 0.5)
+    b = rnd((cout,), 23)
+    gy = rnd((n, cout, h, w), 24)
+    xr = x.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wt, b, padding=1)
+    yr.backward(gy)
+    xg = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    wg = wt.permute(2, 3, 1, 0).contiguous().to(dev)
+    gyg = gy.permute(0, 2, 3, 1).contiguous().to(dev)
+    assert ops.wino_ok(h, w, cin, cout)
+    y = ops.wino_conv(xg, ops.wino_weights(wg), b.to(dev))
+    close(y.permute(0, 3, 1, 2), yr, tol=3e-4)
+    buf = torch.full((n, h, w, cin + 8), 3.0, device=dev)
+    ops.wino_conv(gyg, ops.wino_weights(wg, dgrad=True), None, out=buf[..., 8:], accumulate=True)
+    close(buf[..., 8:].permute(0, 3, 1, 2), xr.grad + 3.0, tol=3e-4)
+    assert float(buf[..., :8].min()) == 3.0 and float(buf[..., :8].max()) == 3.0

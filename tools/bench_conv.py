@@ -39,6 +39,12 @@ for cin, cout, div, k, dil in LAYERS:
     td = timeit(lambda: ops.conv_dgrad(dy, w, dil=dil))
     tw = timeit(lambda: ops.conv_wgrad(x, dy, k, k, dil=dil))
     tot["fwd"] += tf; tot["dgrad"] += td; tot["wgrad"] += tw
+    wino = ""
+    if k == 3 and dil == 1 and ops.wino_ok(h, h, cin, cout):
+        U = ops.wino_weights(w); Ud = ops.wino_weights(w, dgrad=True)
+        twf = timeit(lambda: ops.wino_conv(x, U)); twd = timeit(lambda: ops.wino_conv(dy, Ud))
+        tot["wino_fwd"] = tot.get("wino_fwd", 0.0) + twf; tot["wino_dgrad"] = tot.get("wino_dgrad", 0.0) + twd
+        wino = f" | wino fwd {twf:7.3f} ms {flop/twf/1e9:6.1f} TF dgrad {twd:7.3f} ms {flop/twd/1e9:6.1f} TF"
     print(f"{cin:5d}->{cout:5d} @{h:4d} k{k} d{dil}: fwd {tf:7.3f} ms {flop/tf/1e9:6.1f} TF | dgrad {td:7.3f} ms {flop/td/1e9:6.1f} TF"
-          f" | wgrad {tw:7.3f} ms {flop/tw/1e9:6.1f} TF", flush=True)
+          f" | wgrad {tw:7.3f} ms {flop/tw/1e9:6.1f} TF" + wino, flush=True)
 print("sum ms:", tot)
