@@ -255,6 +255,203 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
     }
 }
 
+
+// ------------------------------------------------------------------------------------------ Winograd weight gradient
+//   dg = G^T [ sum_tiles (B^T d B) .* (A dY A^T) ] G        (same 2.25x saving as the forward)
+// Block = 32 input channels x 64 output channels, all 16 positions (wave w owns positions 4w..4w+3: 8 accumulator tiles).
+// Per batch of 8 tiles each thread transforms the 4x4 x patch of one (tile, cin) and the 2x2 dy tile of two (tile, cout) in
+// registers and writes V[xi][tile][cin], Z[xi][tile][cout] to LDS; the MFMA K dimension is the tile index.  The block walks its
+// range of tiles with the accumulators in registers and writes one Winograd-domain slab [16][cin][cout];
+// `wino_wgrad_reduce_kernel` sums the slabs in a fixed order and applies G^T . G.
+struct WinoWgradArgs {
+    const float* x; int ldx;      // [Nimg, H, W, ldx]
+    const float* dy; int ldy;     // [Nimg, H, W, ldy]
+    float* slabs;                 // [splits][16][cin][cout]
+    int cin, cout, Nimg, H, W, TY, TX, co_chunks;
+    long tiles, tiles_per_split;
+};
+
+constexpr int GT = 8;             // tiles per batch
+constexpr int GCI = 32, GCO = 64;
+
+__global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(WinoWgradArgs g) {
+    __shared__ __attribute__((aligned(16))) float Vs[16 * GT * GCI];    // 16 KB
+    __shared__ __attribute__((aligned(16))) float Zs[16 * GT * GCO];    // 32 KB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int ci0 = (blockIdx.x / g.co_chunks) * GCI, co0 = (blockIdx.x % g.co_chunks) * GCO;
+    const long t_begin = (long)blockIdx.y * g.tiles_per_split;
+    const long t_end = t_begin + g.tiles_per_split < g.tiles ? t_begin + g.tiles_per_split : g.tiles;
+    const int per = g.TY * g.TX;
+    const int rowx = g.W * g.ldx, rowy = g.W * g.ldy;
+
+    const int xt = tid >> 5, xc = tid & 31;            // x loader: (tile, cin)
+    const bool xc_ok = ci0 + xc < g.cin;
+    float rx[16], ry[2][4];
+    auto prefetch = [&](long tb) {
+        {   // x patch of tile tb + xt
+            const long tg = tb + xt;
+            const bool tv = tg < t_end && xc_ok;
+            const long tt = tg < g.tiles ? tg : 0;
+            const int n = (int)(tt / per);
+            const int rem = (int)(tt - (long)n * per);
+            const int ty = rem / g.TX, tx = rem - ty * g.TX;
+            const int h0 = 2 * ty - 1, w0 = 2 * tx - 1;
+            const float* base = g.x + (((long)n * g.H + h0) * g.W + w0) * g.ldx + ci0 + xc;
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const bool ok = tv && (unsigned)(h0 + a) < (unsigned)g.H && (unsigned)(w0 + b) < (unsigned)g.W;
+                    rx[a * 4 + b] = ok ? base[a * rowx + b * g.ldx] : 0.f;
+                }
+        }
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {   // dy tiles: items (tile, cout) = tid, tid + 256
+            const int idx = tid + 256 * v;
+            const int yt = idx >> 6, yc = idx & 63;
+            const long tg = tb + yt;
+            const bool tv = tg < t_end && co0 + yc < g.cout;
+            const long tt = tg < g.tiles ? tg : 0;
+            const int n = (int)(tt / per);
+            const int rem = (int)(tt - (long)n * per);
+            const int ty = rem / g.TX, tx = rem - ty * g.TX;
+            const float* base = g.dy + (((long)n * g.H + 2 * ty) * g.W + 2 * tx) * g.ldy + co0 + yc;
+            ry[v][0] = tv ? base[0] : 0.f;
+            ry[v][1] = tv ? base[g.ldy] : 0.f;
+            ry[v][2] = tv ? base[rowy] : 0.f;
+            ry[v][3] = tv ? base[rowy + g.ldy] : 0.f;
+        }
+    };
+    auto transform_store = [&]() {
+        float tmp[16];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const float d0 = rx[b], d1 = rx[4 + b], d2 = rx[8 + b], d3 = rx[12 + b];
+            tmp[b] = d0 - d2; tmp[4 + b] = d1 + d2; tmp[8 + b] = d2 - d1; tmp[12 + b] = d1 - d3;
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const float v0 = tmp[a * 4], v1 = tmp[a * 4 + 1], v2 = tmp[a * 4 + 2], v3 = tmp[a * 4 + 3];
+            Vs[((a * 4 + 0) * GT + xt) * GCI + xc] = v0 - v2;
+            Vs[((a * 4 + 1) * GT + xt) * GCI + xc] = v1 + v2;
+            Vs[((a * 4 + 2) * GT + xt) * GCI + xc] = v2 - v1;
+            Vs[((a * 4 + 3) * GT + xt) * GCI + xc] = v1 - v3;
+        }
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const int idx = tid + 256 * v;
+            const int yt = idx >> 6, yc = idx & 63;
+            const float y00 = ry[v][0], y01 = ry[v][1], y10 = ry[v][2], y11 = ry[v][3];
+            // Z = A Y A^T, A = [[1,0],[1,1],[1,-1],[0,-1]]
+            const float r[4][2] = {{y00, y01}, {y00 + y10, y01 + y11}, {y00 - y10, y01 - y11}, {-y10, -y11}};
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const float p = r[a][0], q = r[a][1];
+                Zs[((a * 4 + 0) * GT + yt) * GCO + yc] = p;
+                Zs[((a * 4 + 1) * GT + yt) * GCO + yc] = p + q;
+                Zs[((a * 4 + 2) * GT + yt) * GCO + yc] = p - q;
+                Zs[((a * 4 + 3) * GT + yt) * GCO + yc] = -q;
+            }
+        }
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][b][r] = 0.f;
+
+    if (t_begin < t_end) prefetch(t_begin);
+    for (long tb = t_begin; tb < t_end; tb += GT) {
+        __syncthreads();
+        transform_store();
+        __syncthreads();
+        if (tb + GT < t_end) prefetch(tb + GT);
+#pragma unroll
+        for (int xl = 0; xl < 4; ++xl) {
+            const int xi = wid * 4 + xl;
+#pragma unroll
+            for (int s = 0; s < GT / 2; ++s) {
+                const float a = Vs[(xi * GT + 2 * s + lh) * GCI + li];
+                const float b0 = Zs[(xi * GT + 2 * s + lh) * GCO + li];
+                const float b1 = Zs[(xi * GT + 2 * s + lh) * GCO + 32 + li];
+                acc[xl][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[xl][0], 0, 0, 0);
+                acc[xl][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[xl][1], 0, 0, 0);
+            }
+        }
+    }
+
+    float* slab = g.slabs + (long)blockIdx.y * 16 * g.cin * g.cout;
+#pragma unroll
+    for (int xl = 0; xl < 4; ++xl)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int co = co0 + b * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = ci0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (ci < g.cin && co < g.cout) slab[((long)(wid * 4 + xl) * g.cin + ci) * g.cout + co] = acc[xl][b][r];
+            }
+        }
+}
+
+// dw[r][s][ci][co] = (G^T (sum_splits slab) G)[r][s];  block = 32 (ci,co) columns x 8 split-lanes
+__global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __restrict__ slabs, int nsplit, long kn, float* __restrict__ dw) {
+    __shared__ float red[8][16][32];
+    const int col = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const long i = (long)blockIdx.x * 32 + col;
+    float m[16];
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi) m[xi] = 0.f;
+    if (i < kn)
+        for (int k = sl; k < nsplit; k += 8) {
+            const float* p = slabs + (long)k * 16 * kn + i;
+#pragma unroll
+            for (int xi = 0; xi < 16; ++xi) m[xi] += p[(long)xi * kn];
+        }
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi) red[sl][xi][col] = m[xi];
+    __syncthreads();
+    if (sl == 0 && i < kn) {
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+            for (int j = 1; j < 8; ++j) m[xi] += red[j][xi][col];
+        // G^T (3x4) = [[1,.5,.5,0],[0,.5,-.5,0],[0,.5,.5,1]]
+        float t[3][4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            t[0][b] = m[b] + 0.5f * (m[4 + b] + m[8 + b]);
+            t[1][b] = 0.5f * (m[4 + b] - m[8 + b]);
+            t[2][b] = 0.5f * (m[4 + b] + m[8 + b]) + m[12 + b];
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            dw[(long)(r * 3 + 0) * kn + i] = t[r][0] + 0.5f * (t[r][1] + t[r][2]);
+            dw[(long)(r * 3 + 1) * kn + i] = 0.5f * (t[r][1] - t[r][2]);
+            dw[(long)(r * 3 + 2) * kn + i] = 0.5f * (t[r][1] + t[r][2]) + t[r][3];
+        }
+    }
+}
+
+struct WinoWgradPlan { int ci_chunks, co_chunks, splits; long tiles, tps; };
+static WinoWgradPlan wino_wgrad_plan(int n_img, int h, int w, int cin, int cout) {
+    WinoWgradPlan p{};
+    p.ci_chunks = cdiv(cin, GCI); p.co_chunks = cdiv(cout, GCO);
+    p.tiles = (long)n_img * (h / 2) * (w / 2);
+    long splits = cdiv(640, p.ci_chunks * p.co_chunks);
+    const long maxs = cdiv(p.tiles, GT);
+    if (splits > maxs) splits = maxs;
+    if (splits < 1) splits = 1;
+    p.tps = cdiv(cdiv(p.tiles, splits), GT) * (long)GT;
+    p.splits = cdiv(p.tiles, p.tps);
+    return p;
+}
+
 }  // namespace
 
 extern "C" int runet_wino_supported(int h, int w, int cin, int cout) {
@@ -279,5 +476,27 @@ extern "C" int runet_wino_conv(const float* x, int ldx, const float* U, const fl
     a.Nimg = n_img; a.H = h; a.W = w; a.TY = h / 2; a.TX = w / 2; a.tiles = (long)n_img * a.TY * a.TX; a.accumulate = accumulate;
     dim3 grid(cdiv(a.tiles, WT), cdiv(n, WBN));
     hipLaunchKernelGGL(wino_conv_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    RUNET_CHECK_LAUNCH();
+}
+
+extern "C" long runet_wino_wgrad_workspace_floats(int n_img, int h, int w, int cin, int cout) {
+    const WinoWgradPlan p = wino_wgrad_plan(n_img, h, w, cin, cout);
+    return (long)p.splits * 16 * cin * cout;
+}
+
+extern "C" int runet_wino_wgrad(const float* x, int ldx, const float* dy, int ldy, float* dw, float* workspace, long workspace_floats,
+                                int n_img, int h, int w, int cin, int cout, void* stream) {
+    RUNET_REQUIRE(x && dy && dw && workspace, "null pointer");
+    RUNET_REQUIRE(h % 2 == 0 && w % 2 == 0 && cin > 0 && cout > 0, "H and W must be even");
+    RUNET_REQUIRE(ldx >= cin && ldy >= cout, "bad pixel strides");
+    const WinoWgradPlan p = wino_wgrad_plan(n_img, h, w, cin, cout);
+    RUNET_REQUIRE(workspace_floats >= (long)p.splits * 16 * cin * cout, "workspace too small (runet_wino_wgrad_workspace_floats)");
+    hipStream_t st = (hipStream_t)stream;
+    WinoWgradArgs a{};
+    a.x = x; a.ldx = ldx; a.dy = dy; a.ldy = ldy; a.slabs = workspace; a.cin = cin; a.cout = cout; a.Nimg = n_img; a.H = h; a.W = w;
+    a.TY = h / 2; a.TX = w / 2; a.co_chunks = p.co_chunks; a.tiles = p.tiles; a.tiles_per_split = p.tps;
+    hipLaunchKernelGGL(wino_wgrad_kernel, dim3(p.ci_chunks * p.co_chunks, p.splits), dim3(256), 0, st, a);
+    const long kn = (long)cin * cout;
+    hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(cdiv(kn, 32)), dim3(256), 0, st, workspace, p.splits, kn, dw);
     RUNET_CHECK_LAUNCH();
 }

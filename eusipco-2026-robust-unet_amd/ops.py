@@ -164,6 +164,11 @@ def conv_wgrad(x, dy, kh, kw, cin_w=None, dil=1, out=None):
     cin_w = cin if cin_w is None else cin_w
     if out is None:
         out = torch.empty((kh, kw, cin_w, cout), device=x.device, dtype=torch.float32)
+    if USE_WINOGRAD and kh == 3 and dil == 1 and cin_w == cin and h % 2 == 0 and w % 2 == 0 and cin >= 16:
+        nws = lib.runet_wino_wgrad_workspace_floats(n, h, w, cin, cout)
+        ws = workspace(nws, x.device)
+        check(lib.runet_wino_wgrad(x.data_ptr(), ld(x), dy.data_ptr(), ld(dy), out.data_ptr(), ws.data_ptr(), ws.numel(), n, h, w, cin, cout, stream()))
+        return out
     nws = lib.runet_conv_wgrad_workspace_floats(n, h, w, cin_w, cout, kh, kw)
     ws = workspace(nws, x.device)
     check(lib.runet_conv_wgrad(x.data_ptr(), ld(x), dy.data_ptr(), ld(dy), out.data_ptr(), ws.data_ptr(), ws.numel(),

@@ -63,6 +63,12 @@ int runet_wino_weights(const float* w_hwio, float* U, int cin, int cout, int dgr
 int runet_wino_conv(const float* x, int ldx, const float* U, const float* bias, float* y, int ldy, int n_img, int h, int w, int k, int n,
                     int accumulate, void* stream);
 
+/* Winograd-domain weight gradient of the same convolutions: dw[3][3][cin][cout] = G^T [sum_tiles (B^T x B).*(A dy A^T)] G.
+ * workspace: >= runet_wino_wgrad_workspace_floats floats (partial slabs, summed in a fixed order).  H, W even. */
+long runet_wino_wgrad_workspace_floats(int n_img, int h, int w, int cin, int cout);
+int runet_wino_wgrad(const float* x, int ldx, const float* dy, int ldy, float* dw, float* workspace, long workspace_floats, int n_img,
+                     int h, int w, int cin, int cout, void* stream);
+
 /* ---- channel statistics / BatchNorm2d / ReLU / Dropout2d (Main_Final.py:158,160,162,163,173,127,132,137,210,211) ----
  * Scratch buffers ("workspace") are caller-owned; runet_reduce_workspace_floats gives a sufficient size. */
 long runet_reduce_workspace_floats(int n_img, int hw, int c);
