@@ -4,7 +4,7 @@
 //
 //   Y = A^T [ (G g G^T) .* (B^T d B) ] A      per 2x2 output tile, 4x4 input patch d, 3x3 filter g
 //
-// * `wino_weight_kernel` transforms the HWIO weight once per use into U[16][K][N] (forward: K = cin, N = cout; data
+// * `wino_weight_kernel` transforms the HWIO weight once per use into U[16][K/4][N][4] (forward: K = cin, N = cout; data
 //   gradient: the 180-degree rotated filter with K = cout, N = cin).
 // * `wino_conv_kernel`: one block = 32 tiles (one 32-row MFMA tile) x 64 output channels.  Per 16-channel chunk every thread
 //   loads the 4x4 patch of one (tile, channel pair) straight from NHWC global memory (8 lanes cover the 64 contiguous bytes
@@ -21,7 +21,7 @@ namespace {
 
 struct WinoArgs {
     const float* x; int ldx;      // [Nimg, H, W, ldx], K channels
-    const float* U;               // [16][K][N]
+    const float* U;               // [16][K/4][N][4]
     const float* bias;            // [N] or nullptr
     float* y; int ldy;            // [Nimg, H, W, ldy], N channels
     int K, N;
@@ -37,16 +37,19 @@ constexpr int VLD = 20;           // padded k-stride of a V row (conflict-free d
 __global__ __launch_bounds__(256, 2) void wino_conv_kernel(WinoArgs g) {
     __shared__ __attribute__((aligned(16))) float V[16 * WT * VLD];     // 40 KB; reused as M[16][32][16] in the epilogue
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform: U pointers stay in SGPRs
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform: U offsets stay in SGPRs
     const int li = lane & 31, lh = lane >> 5;
     const long t0 = (long)blockIdx.x * WT;
     const int n0 = blockIdx.y * WBN;
+
+    // Every global read is UNCONDITIONAL (a masked lane reads element 0 and the value is then zeroed): no branches around
+    // loads, so the compiler's vmcnt bookkeeping stays exact and the prefetches really overlap the MFMAs.
 
     // ---- loader role: (tile lt, channel pair k2) ----
     const int lt = tid >> 3, k2 = tid & 7;
     const long tg = t0 + lt;
     unsigned vmask = 0;           // bit (a*4+b): patch pixel in bounds
-    int pbase = 0;                // element offset of patch pixel (0,0) (may be out of bounds; only masked pixels are read)
+    int poff[16];                 // element offset of each patch pixel for this lane (0 when masked)
     {
         const bool tv = tg < g.tiles;
         const long tt = tv ? tg : 0;
@@ -55,32 +58,29 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel(WinoArgs g) {
         const int rem = (int)(tt - (long)n * per);
         const int ty = rem / g.TX, tx = rem - ty * g.TX;
         const int h0 = 2 * ty - 1, w0 = 2 * tx - 1;
-        pbase = (int)((((long)n * g.H + h0) * g.W + w0) * g.ldx + 2 * k2);
-        if (tv) {
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b)
-                    if ((unsigned)(h0 + a) < (unsigned)g.H && (unsigned)(w0 + b) < (unsigned)g.W) vmask |= 1u << (a * 4 + b);
-        }
-    }
-    const int rowstride = g.W * g.ldx;
-
-    float2 raw[16];
-    auto load_patch = [&](int c0) {
+        const int pbase = (int)((((long)n * g.H + h0) * g.W + w0) * g.ldx + 2 * k2);
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
-                float2 v = make_float2(0.f, 0.f);
-                const float* xb = g.x + (a * rowstride + b * g.ldx + c0);          // wave-uniform part
-                if (vmask & (1u << (a * 4 + b))) v = *reinterpret_cast<const float2*>(xb + pbase);
-                raw[a * 4 + b] = v;
+                const bool ok = tv && (unsigned)(h0 + a) < (unsigned)g.H && (unsigned)(w0 + b) < (unsigned)g.W;
+                poff[a * 4 + b] = ok ? pbase + (a * g.W + b) * g.ldx : 0;
+                if (ok) vmask |= 1u << (a * 4 + b);
             }
+    }
+
+    float2 raw[16];
+    auto load_patch = [&](int c0) {
+        const float* xc = g.x + c0;            // wave-uniform
+#pragma unroll
+        for (int i = 0; i < 16; ++i) raw[i] = *reinterpret_cast<const float2*>(xc + poff[i]);
     };
     auto transform_store = [&]() {
         // B^T d B on both channels; V[xi][lt][2*k2 .. 2*k2+1]
         float2 tmp[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (!(vmask & (1u << i))) raw[i] = make_float2(0.f, 0.f);
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             const float2 d0 = raw[b], d1 = raw[4 + b], d2 = raw[8 + b], d3 = raw[12 + b];
@@ -111,53 +111,60 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel(WinoArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][b][r] = 0.f;
 
+    // U is stored [16][K/4][N][4]: lane (j, h) reads ONE float4 = the 4 consecutive k it feeds to 4 MFMAs
+    const int K4 = g.K >> 2;
+    const f32x4* U4 = reinterpret_cast<const f32x4*>(g.U);
+    int uoff[2];              // columns n >= N read element 0 instead: their products land in output columns that are never stored
+#pragma unroll
+    for (int b = 0; b < 2; ++b) uoff[b] = (n0 + b * 32 + li < g.N) ? lh * g.N + b * 32 + li : 0;
+    f32x4 bfa[2][2], bfb[2][2];
+    auto load_u = [&](int xl, int c0, f32x4 (&bf)[2][2]) {
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+            const f32x4* up = U4 + ((long)((wid * 4 + xl) * K4 + (c0 >> 2) + kh * 2) * g.N + n0);      // wave-uniform
+#pragma unroll
+            for (int b = 0; b < 2; ++b) bf[kh][b] = up[uoff[b]];
+        }
+    };
+    auto mma = [&](int xl, const f32x4 (&bf)[2][2]) {
+        const int xi = wid * 4 + xl;
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(&V[(xi * WT + li) * VLD + 4 * lh]);
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(&V[(xi * WT + li) * VLD + 8 + 4 * lh]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[xl][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q], bf[0][b][q], acc[xl][b], 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[xl][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q], bf[1][b][q], acc[xl][b], 0, 0, 0);
+    };
+
     const int nchunks = g.K >> 4;
     load_patch(0);
+    load_u(0, 0, bfa);
     for (int ch = 0; ch < nchunks; ++ch) {
         const int c0 = ch * 16;
+        const int cn = (ch + 1 < nchunks) ? c0 + 16 : c0;      // last chunk: harmless re-read, keeps the code branch-free
         __syncthreads();                       // previous chunk's MFMA reads of V are done
         transform_store();
         __syncthreads();
-        if (ch + 1 < nchunks) load_patch(c0 + 16);     // in flight during the MFMAs
-        // U fragments: double-buffered in registers, the next position's 16 loads are issued before this position's 16 MFMAs
-        // (sched_barrier keeps the compiler from hoisting all 64 loads to the top, which spills)
-        float bfa[2][2][4], bfb[2][2][4];
-        auto load_u = [&](int xl, float (&bf)[2][2][4]) {
-            const float* Ub = g.U + ((long)(wid * 4 + xl) * g.K + c0) * g.N + n0;      // wave-uniform
-            const int uoff = 4 * lh * g.N + li;                                        // per-lane
-#pragma unroll
-            for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int b = 0; b < 2; ++b) {
-                        const float* up = Ub + ((kh * 8 + q) * g.N + b * 32);
-                        bf[kh][b][q] = (n0 + b * 32 + li < g.N) ? up[uoff] : 0.f;
-                    }
-        };
-        auto mma = [&](int xl, const float (&bf)[2][2][4]) {
-            const int xi = wid * 4 + xl;
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(&V[(xi * WT + li) * VLD + 4 * lh]);
-            const f32x4 a1 = *reinterpret_cast<const f32x4*>(&V[(xi * WT + li) * VLD + 8 + 4 * lh]);
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) acc[xl][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q], bf[0][b][q], acc[xl][b], 0, 0, 0);
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) acc[xl][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q], bf[1][b][q], acc[xl][b], 0, 0, 0);
-        };
-        load_u(0, bfa);
+        // the sched_barriers pin each group of loads in FRONT of the 16 MFMAs it overlaps (the scheduler otherwise sinks the
+        // loads to the end of the region, two MFMAs ahead of their first use)
+        load_u(1, c0, bfb);
         __builtin_amdgcn_sched_barrier(0);
-        load_u(1, bfb);
-        mma(0, bfa);
+        mma(0, bfa);                           // its U fragments were requested during the previous chunk
         __builtin_amdgcn_sched_barrier(0);
-        load_u(2, bfa);
+        load_patch(cn);                        // next chunk's patch: in flight during the rest of this chunk's MFMAs
+        load_u(2, c0, bfa);
+        __builtin_amdgcn_sched_barrier(0);
         mma(1, bfb);
         __builtin_amdgcn_sched_barrier(0);
-        load_u(3, bfb);
+        load_u(3, c0, bfb);
+        __builtin_amdgcn_sched_barrier(0);
         mma(2, bfa);
+        __builtin_amdgcn_sched_barrier(0);
+        load_u(0, cn, bfa);                    // position 0 of the NEXT chunk, in flight across the two barriers
         __builtin_amdgcn_sched_barrier(0);
         mma(3, bfb);
         __builtin_amdgcn_sched_barrier(0);
@@ -244,7 +251,8 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
         t[3][s] = gm[2][s];
     }
     const int K = dgrad ? cout : cin, N = dgrad ? cin : cout;
-    const long kn = dgrad ? ((long)co * N + ci) : ((long)ci * N + co);
+    const int k = dgrad ? co : ci, n = dgrad ? ci : co;
+    const long kn = ((long)(k >> 2) * N + n) * 4 + (k & 3);          // blocked layout [K/4][N][4]
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
         const float u0 = t[a][0], u1 = 0.5f * (t[a][0] + t[a][1] + t[a][2]), u2 = 0.5f * (t[a][0] - t[a][1] + t[a][2]), u3 = t[a][2];
@@ -470,7 +478,8 @@ extern "C" int runet_wino_conv(const float* x, int ldx, const float* U, const fl
     RUNET_REQUIRE(x && U && y, "null pointer");
     RUNET_REQUIRE(runet_wino_supported(h, w, k, n), "shape not supported by the Winograd kernel (H, W even; K multiple of 16; N even)");
     RUNET_REQUIRE(ldx >= k && ldx % 2 == 0 && ldy >= n && ldy % 2 == 0, "pixel strides must be even and cover the channels");
-    RUNET_REQUIRE(((uintptr_t)x % 8) == 0 && ((uintptr_t)y % 8) == 0 && ((uintptr_t)U % 4) == 0 && (!bias || ((uintptr_t)bias % 8) == 0), "alignment");
+    RUNET_REQUIRE(((uintptr_t)x % 8) == 0 && ((uintptr_t)y % 8) == 0 && ((uintptr_t)U % 16) == 0 && (!bias || ((uintptr_t)bias % 8) == 0), "alignment");
+    RUNET_REQUIRE((long)n_img * h * w * ldx < (1L << 29) && 16L * k * n < (1L << 29), "tensor too large for 32-bit buffer offsets");
     WinoArgs a{};
     a.x = x; a.ldx = ldx; a.U = U; a.bias = bias; a.y = y; a.ldy = ldy; a.K = k; a.N = n;
     a.Nimg = n_img; a.H = h; a.W = w; a.TY = h / 2; a.TX = w / 2; a.tiles = (long)n_img * a.TY * a.TX; a.accumulate = accumulate;
