@@ -377,8 +377,8 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(WinoWgradArgs g) {
     for (long tb = t_begin; tb < t_end; tb += GT) {
         __syncthreads();
         transform_store();
+        if (tb + GT < t_end) prefetch(tb + GT);     // issued before the barrier: in flight during barrier + MFMAs
         __syncthreads();
-        if (tb + GT < t_end) prefetch(tb + GT);
 #pragma unroll
         for (int xl = 0; xl < 4; ++xl) {
             const int xi = wid * 4 + xl;
