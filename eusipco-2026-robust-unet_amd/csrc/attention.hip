@@ -146,27 +146,30 @@ __global__ __launch_bounds__(256) void sa_conv7_kernel(const float* __restrict__
 }
 
 // out = relu((t2*A+B)*sa + res), res = r*rs + rh (conv shortcut) or r (identity, rs == nullptr)
+// grid (chunks, images): a thread owns 4 channels (coefficients in registers) and every `rows`-th pixel of its chunk
 __global__ __launch_bounds__(TPB) void rb_out_kernel(const float* __restrict__ t2, int ld, const float* __restrict__ A,
                                                      const float* __restrict__ B, const float* __restrict__ sa,
                                                      const float* __restrict__ r, int ldr, const float* __restrict__ rs,
-                                                     const float* __restrict__ rh, float* __restrict__ out, int ldo, long P,
-                                                     int HW, int C) {
-    const int cvec = C / 4;
-    const long total = P * cvec;
-    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
-        const long p = i / cvec;
-        const int c = (int)(i - p * cvec) * 4;
-        const int n = (int)(p / HW);
-        const f32x4 t = *reinterpret_cast<const f32x4*>(t2 + p * ld + c);
-        const f32x4 a = *reinterpret_cast<const f32x4*>(A + (long)n * C + c);
-        const f32x4 b = *reinterpret_cast<const f32x4*>(B + (long)n * C + c);
-        f32x4 res = *reinterpret_cast<const f32x4*>(r + p * ldr + c);
-        if (rs) res = res * *reinterpret_cast<const f32x4*>(rs + c) + *reinterpret_cast<const f32x4*>(rh + c);
-        const float s = sa[p];
+                                                     const float* __restrict__ rh, float* __restrict__ out, int ldo, int HW, int C,
+                                                     int pix_per_chunk) {
+    const int cvec = C / 4, rows = TPB / cvec, tid = threadIdx.x;
+    const int col = tid % cvec, row = tid / cvec;
+    if (row >= rows) return;
+    const int n = blockIdx.y, c = col * 4;
+    const int p0 = blockIdx.x * pix_per_chunk, p1 = min(HW, p0 + pix_per_chunk);
+    const f32x4 a = *reinterpret_cast<const f32x4*>(A + (long)n * C + c);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(B + (long)n * C + c);
+    f32x4 s4 = {1.f, 1.f, 1.f, 1.f}, h4 = {0.f, 0.f, 0.f, 0.f};
+    if (rs) { s4 = *reinterpret_cast<const f32x4*>(rs + c); h4 = *reinterpret_cast<const f32x4*>(rh + c); }
+    const long ib = (long)n * HW;
+    for (int p = p0 + row; p < p1; p += rows) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(t2 + (ib + p) * ld + c);
+        const f32x4 res = *reinterpret_cast<const f32x4*>(r + (ib + p) * ldr + c) * s4 + h4;
+        const float s = sa[ib + p];
         f32x4 o = (t * a + b) * s + res;
 #pragma unroll
         for (int q = 0; q < 4; ++q) o[q] = fmaxf(o[q], 0.f);
-        *reinterpret_cast<f32x4*>(out + p * ldo + c) = o;
+        *reinterpret_cast<f32x4*>(out + (ib + p) * ldo + c) = o;
     }
 }
 
@@ -382,37 +385,47 @@ __global__ void ca_bwd_final_kernel(const float* __restrict__ sdu, const float* 
     }
 }
 
-// ---- backward 3: dt2 = s2*(du0 - k1 - xhat*k2)
+// ---- backward 3: dt2 = s2*(du0 - k1 - xhat*k2);  same thread layout as rb_out
 __global__ __launch_bounds__(TPB) void rb_bwd3_kernel(const float* __restrict__ dv, int lddv, const float* __restrict__ t2, int ld,
                                                       const float* __restrict__ sa, const float* __restrict__ dsm,
                                                       const int* __restrict__ amax, const float* __restrict__ ca,
                                                       const float* __restrict__ davg, const float* __restrict__ dmx,
                                                       const int* __restrict__ idx, const float* __restrict__ mean2,
                                                       const float* __restrict__ invstd2, const float* __restrict__ s2,
-                                                      const float* __restrict__ sums2, float* __restrict__ dt2, int lddt, long P,
-                                                      int HW, int C, float inv_m) {
-    const int cvec = C / 4;
-    const long total = P * cvec;
+                                                      const float* __restrict__ sums2, float* __restrict__ dt2, int lddt, int HW, int C,
+                                                      int pix_per_chunk, float inv_m) {
+    const int cvec = C / 4, rows = TPB / cvec, tid = threadIdx.x;
+    const int col = tid % cvec, row = tid / cvec;
+    if (row >= rows) return;
+    const int n = blockIdx.y, c = col * 4;
+    const int p0 = blockIdx.x * pix_per_chunk, p1 = min(HW, p0 + pix_per_chunk);
     const float invC = 1.0f / (float)C, invHW = 1.0f / (float)HW;
-    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
-        const long p = i / cvec;
-        const int c = (int)(i - p * cvec) * 4;
-        const int n = (int)(p / HW);
-        const int hw = (int)(p - (long)n * HW);
-        const f32x4 d = *reinterpret_cast<const f32x4*>(dv + p * lddv + c);
-        const f32x4 t = *reinterpret_cast<const f32x4*>(t2 + p * ld + c);
-        const float v = sa[p], g0 = dsm[p * 2] * invC, g1 = dsm[p * 2 + 1];
-        const int am = amax[p];
+    // dt2 = s2*( du*ca + davg/HW + [p==idx]*dmx - k1 - (t2-mean)*invstd*k2 ) = du*(s2*ca) + t2*e + f + [p==idx]*(s2*dmx)
+    float cc[4], e[4], f[4], dmxs[4];
+    int ix[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int k = n * C + c + q;
+        const float s = s2[c + q], is = invstd2[c + q], k1 = sums2[C + c + q] * inv_m, k2 = sums2[c + q] * inv_m;
+        cc[q] = s * ca[k];
+        e[q] = -s * is * k2;
+        f[q] = s * (davg[k] * invHW - k1 + mean2[c + q] * is * k2);
+        dmxs[q] = s * dmx[k];
+        ix[q] = idx[k];
+    }
+    const long ib = (long)n * HW;
+    for (int p = p0 + row; p < p1; p += rows) {
+        const f32x4 d = *reinterpret_cast<const f32x4*>(dv + (ib + p) * lddv + c);
+        const f32x4 t = *reinterpret_cast<const f32x4*>(t2 + (ib + p) * ld + c);
+        const float v = sa[ib + p], g0 = dsm[(ib + p) * 2] * invC, g1 = dsm[(ib + p) * 2 + 1];
+        const int am = amax[ib + p];
         f32x4 r;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int k = n * C + c + q;
             const float du = d[q] * v + g0 + ((c + q) == am ? g1 : 0.f);
-            const float du0 = du * ca[k] + davg[k] * invHW + (idx[k] == hw ? dmx[k] : 0.f);
-            const float xh = (t[q] - mean2[c + q]) * invstd2[c + q];
-            r[q] = s2[c + q] * (du0 - sums2[C + c + q] * inv_m - xh * sums2[c + q] * inv_m);
+            r[q] = du * cc[q] + t[q] * e[q] + f[q] + (ix[q] == p ? dmxs[q] : 0.f);
         }
-        *reinterpret_cast<f32x4*>(dt2 + p * lddt + c) = r;
+        *reinterpret_cast<f32x4*>(dt2 + (ib + p) * lddt + c) = r;
     }
 }
 
@@ -439,20 +452,23 @@ __global__ __launch_bounds__(TPB) void ag_psi_kernel(const float* __restrict__ g
         if (sub == 0) s[p] = acc + bpsi[0];
     }
 }
-// att[p][c] = xs[p][c] * sigmoid(s[p]*sp + hp)
+// att[p][c] = xs[p][c] * sigmoid(s[p]*sp + hp);  thread = 4 channels x strided pixels (flat pixel index, no per-image state)
 __global__ __launch_bounds__(TPB) void ag_out_kernel(const float* __restrict__ xs, int ldx, const float* __restrict__ s,
                                                      const float* __restrict__ sp, const float* __restrict__ hp,
-                                                     float* __restrict__ out, int ldo, long P, int C) {
-    const int cvec = C / 4;
-    const long total = P * cvec;
+                                                     float* __restrict__ out, int ldo, long P, int C, long pix_per_chunk) {
+    const int cvec = C / 4, rows = TPB / cvec, tid = threadIdx.x;
+    const int col = tid % cvec, row = tid / cvec;
+    if (row >= rows) return;
+    const int c = col * 4;
+    const long p0 = (long)blockIdx.x * pix_per_chunk;
+    const long p1 = p0 + pix_per_chunk < P ? p0 + pix_per_chunk : P;
     const float a = sp[0], b = hp[0];
-    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
-        const long p = i / cvec;
-        const int c = (int)(i - p * cvec) * 4;
+    for (long p = p0 + row; p < p1; p += rows) {
         const float sig = sigmoidf_(s[p] * a + b);
         *reinterpret_cast<f32x4*>(out + p * ldo + c) = *reinterpret_cast<const f32x4*>(xs + p * ldx + c) * sig;
     }
 }
+
 // dsbn[p] = (sum_c datt*xs) * sig*(1-sig);  dxs[p][c] = datt*sig
 __global__ __launch_bounds__(TPB) void ag_bwd1_kernel(const float* __restrict__ datt, int ldd, const float* __restrict__ xs, int ldx,
                                                       const float* __restrict__ s, const float* __restrict__ sp,
@@ -582,6 +598,16 @@ inline int ew_grid(long total_vec) {
     if (b < 1) b = 1;
     return (int)b;
 }
+inline int stream_chunks(int HW, int C, int& ppc) {
+    const int rows = TPB / (C / 4);
+    long per_img = ((long)HW * C + 16383) / 16384;
+    const long maxc = (HW + rows - 1) / rows;
+    if (per_img > maxc) per_img = maxc;
+    if (per_img > 4096) per_img = 4096;
+    if (per_img < 1) per_img = 1;
+    ppc = (int)((HW + per_img - 1) / per_img);
+    return (int)((HW + ppc - 1) / ppc);
+}
 inline void chunking(long P, int C, long& chunks, long& ppc) {
     chunks = (P * C + 32767) / 32768;
     if (chunks > 2048) chunks = 2048;
@@ -624,8 +650,11 @@ extern "C" int runet_rb_out(const float* t2, int ld, const float* A, const float
                             const float* rs, const float* rh, float* out, int ldo, long pixels, int hw, int c, void* stream) {
     RUNET_REQUIRE(t2 && A && B && sa && r && out, "null pointer");
     REQ_C4(c);
-    hipLaunchKernelGGL(rb_out_kernel, dim3(ew_grid(pixels * (c / 4))), dim3(TPB), 0, (hipStream_t)stream, t2, ld, A, B, sa, r, ldr, rs, rh, out,
-                       ldo, pixels, hw, c);
+    RUNET_REQUIRE(pixels % hw == 0, "pixels must be a whole number of images");
+    int ppc;
+    const int chunks = stream_chunks(hw, c, ppc);
+    hipLaunchKernelGGL(rb_out_kernel, dim3(chunks, (int)(pixels / hw)), dim3(TPB), 0, (hipStream_t)stream, t2, ld, A, B, sa, r, ldr, rs, rh, out,
+                       ldo, hw, c, ppc);
     RUNET_CHECK_LAUNCH();
 }
 
@@ -694,8 +723,11 @@ extern "C" int runet_rb_bwd3(const float* dv, int lddv, const float* t2, int ld,
                              long m_total, void* stream) {
     RUNET_REQUIRE(dv && t2 && sa && dsm && amax && ca && davg && dmx && idx && mean2 && invstd2 && s2 && sums2 && dt2, "null pointer");
     REQ_C4(c);
-    hipLaunchKernelGGL(rb_bwd3_kernel, dim3(ew_grid(pixels * (c / 4))), dim3(TPB), 0, (hipStream_t)stream, dv, lddv, t2, ld, sa, dsm, amax, ca, davg,
-                       dmx, idx, mean2, invstd2, s2, sums2, dt2, lddt, pixels, hw, c, 1.0f / (float)(m_total > 0 ? m_total : pixels));
+    RUNET_REQUIRE(pixels % hw == 0, "pixels must be a whole number of images");
+    int ppc;
+    const int chunks = stream_chunks(hw, c, ppc);
+    hipLaunchKernelGGL(rb_bwd3_kernel, dim3(chunks, (int)(pixels / hw)), dim3(TPB), 0, (hipStream_t)stream, dv, lddv, t2, ld, sa, dsm, amax, ca, davg,
+                       dmx, idx, mean2, invstd2, s2, sums2, dt2, lddt, hw, c, ppc, 1.0f / (float)(m_total > 0 ? m_total : pixels));
     RUNET_CHECK_LAUNCH();
 }
 
@@ -711,7 +743,9 @@ extern "C" int runet_ag_out(const float* xs, int ldx, const float* s, const floa
                             int c, void* stream) {
     RUNET_REQUIRE(xs && s && sp && hp && out, "null pointer");
     REQ_C4(c);
-    hipLaunchKernelGGL(ag_out_kernel, dim3(ew_grid(pixels * (c / 4))), dim3(TPB), 0, (hipStream_t)stream, xs, ldx, s, sp, hp, out, ldo, pixels, c);
+    long chunks, ppc;
+    chunking(pixels, c, chunks, ppc);
+    hipLaunchKernelGGL(ag_out_kernel, dim3((int)chunks), dim3(TPB), 0, (hipStream_t)stream, xs, ldx, s, sp, hp, out, ldo, pixels, c, ppc);
     RUNET_CHECK_LAUNCH();
 }
 

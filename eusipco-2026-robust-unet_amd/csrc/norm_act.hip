@@ -170,32 +170,40 @@ __global__ void bn_finalize_kernel(const float* __restrict__ mean_nc, const floa
     if (save_mean) { save_mean[c] = (float)mean; save_invstd[c] = (float)invstd; }
 }
 
+// Streaming kernels use a division-free layout: grid (chunks, images); a thread owns VEC consecutive channels (its per-channel
+// coefficients live in registers) and every `rows`-th pixel of its chunk, so the inner loop is loads, FMAs and one pointer add.
 template <int VEC>
 __global__ __launch_bounds__(TPB) void bn_apply_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy,
-                                                       long P, int HW, int C, const float* __restrict__ scale,
+                                                       int HW, int C, int pix_per_chunk, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, const float* __restrict__ mask, int relu) {
-    const int cvec = C / VEC;
-    const long total = P * cvec;
-    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
-        const long p = i / cvec;
-        const int c = (int)(i - p * cvec) * VEC;
+    const int cvec = C / VEC, rows = TPB / cvec, tid = threadIdx.x;
+    const int col = tid % cvec, row = tid / cvec;
+    if (row >= rows) return;
+    const int n = blockIdx.y;
+    const int p0 = blockIdx.x * pix_per_chunk, p1 = min(HW, p0 + pix_per_chunk);
+    float sc[VEC], sh[VEC], mk[VEC];
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) {
+        const int c = col * VEC + q;
+        sc[q] = scale[c]; sh[q] = shift[c]; mk[q] = mask ? mask[(long)n * C + c] : 1.f;
+    }
+    const long ib = (long)n * HW;
+    for (int p = p0 + row; p < p1; p += rows) {
         float v[VEC];
         if constexpr (VEC == 4) {
-            const f32x4 t = *reinterpret_cast<const f32x4*>(x + p * ldx + c);
+            const f32x4 t = *reinterpret_cast<const f32x4*>(x + (ib + p) * ldx + col * 4);
             v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
-        } else v[0] = x[p * ldx + c];
-        const int n = (int)(p / HW);
+        } else v[0] = x[(ib + p) * ldx + col];
 #pragma unroll
         for (int q = 0; q < VEC; ++q) {
-            float r = v[q] * scale[c + q] + shift[c + q];
+            float r = v[q] * sc[q] + sh[q];
             if (relu) r = fmaxf(r, 0.f);
-            if (mask) r *= mask[(long)n * C + c + q];
-            v[q] = r;
+            v[q] = r * mk[q];
         }
         if constexpr (VEC == 4) {
             f32x4 t = {v[0], v[1], v[2], v[3]};
-            *reinterpret_cast<f32x4*>(y + p * ldy + c) = t;
-        } else y[p * ldy + c] = v[0];
+            *reinterpret_cast<f32x4*>(y + (ib + p) * ldy + col * 4) = t;
+        } else y[(ib + p) * ldy + col] = v[0];
     }
 }
 
@@ -281,41 +289,50 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_final(const float* __restri
 template <int VEC>
 __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ x,
                                                            int ldx, const float* __restrict__ act, int ldact, float* __restrict__ dx,
-                                                           int lddx, long P, int HW, int C, const float* __restrict__ mean,
+                                                           int lddx, int HW, int C, int pix_per_chunk, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ scale,
                                                            const float* __restrict__ sums, const float* __restrict__ mask, float inv_m) {
-    const int cvec = C / VEC;
-    const long total = P * cvec;
-    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
-        const long p = i / cvec;
-        const int c = (int)(i - p * cvec) * VEC;
-        const int n = (int)(p / HW);
+    const int cvec = C / VEC, rows = TPB / cvec, tid = threadIdx.x;
+    const int col = tid % cvec, row = tid / cvec;
+    if (row >= rows) return;
+    const int n = blockIdx.y;
+    const int p0 = blockIdx.x * pix_per_chunk, p1 = min(HW, p0 + pix_per_chunk);
+    // dx = sc*(g - k1 - xhat*k2) = g*sc + x*a + b  with a = -sc*k2*invstd, b = sc*(mean*invstd*k2 - k1)
+    float sc[VEC], ca[VEC], cb[VEC], mk[VEC];
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) {
+        const int c = col * VEC + q;
+        const float s = scale[c], k1 = sums[C + c] * inv_m, k2 = sums[c] * inv_m, is = invstd[c];
+        sc[q] = s; ca[q] = -s * k2 * is; cb[q] = s * (mean[c] * is * k2 - k1);
+        mk[q] = mask ? mask[(long)n * C + c] : 1.f;
+    }
+    const long ib = (long)n * HW;
+    for (int p = p0 + row; p < p1; p += rows) {
         float g[VEC], xv[VEC], av[VEC];
         if constexpr (VEC == 4) {
-            const f32x4 t = *reinterpret_cast<const f32x4*>(dy + p * lddy + c);
-            const f32x4 u = *reinterpret_cast<const f32x4*>(x + p * ldx + c);
+            const f32x4 t = *reinterpret_cast<const f32x4*>(dy + (ib + p) * lddy + col * 4);
+            const f32x4 u = *reinterpret_cast<const f32x4*>(x + (ib + p) * ldx + col * 4);
             g[0] = t[0]; g[1] = t[1]; g[2] = t[2]; g[3] = t[3];
             xv[0] = u[0]; xv[1] = u[1]; xv[2] = u[2]; xv[3] = u[3];
             if (act) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(act + p * ldact + c);
+                const f32x4 a = *reinterpret_cast<const f32x4*>(act + (ib + p) * ldact + col * 4);
                 av[0] = a[0]; av[1] = a[1]; av[2] = a[2]; av[3] = a[3];
             }
         } else {
-            g[0] = dy[p * lddy + c]; xv[0] = x[p * ldx + c];
-            if (act) av[0] = act[p * ldact + c];
+            g[0] = dy[(ib + p) * lddy + col]; xv[0] = x[(ib + p) * ldx + col];
+            if (act) av[0] = act[(ib + p) * ldact + col];
         }
         float r[VEC];
 #pragma unroll
         for (int q = 0; q < VEC; ++q) {
             float gg = g[q];
-            if (act) gg = (av[q] > 0.f) ? gg * (mask ? mask[(long)n * C + c + q] : 1.f) : 0.f;
-            const float xh = (xv[q] - mean[c + q]) * invstd[c + q];
-            r[q] = scale[c + q] * (gg - sums[C + c + q] * inv_m - xh * sums[c + q] * inv_m);
+            if (act) gg = (av[q] > 0.f) ? gg * mk[q] : 0.f;
+            r[q] = gg * sc[q] + xv[q] * ca[q] + cb[q];
         }
         if constexpr (VEC == 4) {
             f32x4 t = {r[0], r[1], r[2], r[3]};
-            *reinterpret_cast<f32x4*>(dx + p * lddx + c) = t;
-        } else dx[p * lddx + c] = r[0];
+            *reinterpret_cast<f32x4*>(dx + (ib + p) * lddx + col * 4) = t;
+        } else dx[(ib + p) * lddx + col] = r[0];
     }
 }
 
@@ -374,6 +391,16 @@ inline int pick_chunks(int N, int HW, int C, int rows) {
     long maxc = (HW + rows - 1) / rows;
     if (per_img > maxc) per_img = maxc;
     return (int)per_img;
+}
+// chunks per image for the streaming kernels: ~16 vector loads per thread, at least one pass of `rows` pixels per chunk
+inline int stream_chunks(int N, int HW, int C, int rows, int& ppc) {
+    long per_img = ((long)HW * C + 16383) / 16384;
+    const long maxc = (HW + rows - 1) / rows;
+    if (per_img > maxc) per_img = maxc;
+    if (per_img > 4096) per_img = 4096;
+    if (per_img < 1) per_img = 1;
+    ppc = (int)((HW + per_img - 1) / per_img);
+    return (int)((HW + ppc - 1) / ppc);
 }
 inline int ew_grid(long total_vec) {
     long b = (total_vec + TPB - 1) / TPB;
@@ -439,8 +466,12 @@ extern "C" int runet_bn_apply(const float* x, int ldx, float* y, int ldy, long p
     REQ_VEC(c);
     RUNET_REQUIRE(pixels > 0 && hw > 0 && ldx >= c && ldy >= c, "bad shape");
     hipStream_t st = (hipStream_t)stream;
-    if (c % 4 == 0) hipLaunchKernelGGL((bn_apply_kernel<4>), dim3(ew_grid(pixels * (c / 4))), dim3(TPB), 0, st, x, ldx, y, ldy, pixels, hw, c, scale, shift, mask_nc, relu);
-    else hipLaunchKernelGGL((bn_apply_kernel<1>), dim3(ew_grid(pixels * c)), dim3(TPB), 0, st, x, ldx, y, ldy, pixels, hw, c, scale, shift, mask_nc, relu);
+    RUNET_REQUIRE(pixels % hw == 0, "pixels must be a whole number of images");
+    const int nimg = (int)(pixels / hw), vec = (c % 4 == 0) ? 4 : 1;
+    int ppc;
+    const int chunks = stream_chunks(nimg, hw, c, TPB / (c / vec), ppc);
+    if (vec == 4) hipLaunchKernelGGL((bn_apply_kernel<4>), dim3(chunks, nimg), dim3(TPB), 0, st, x, ldx, y, ldy, hw, c, ppc, scale, shift, mask_nc, relu);
+    else hipLaunchKernelGGL((bn_apply_kernel<1>), dim3(chunks, nimg), dim3(TPB), 0, st, x, ldx, y, ldy, hw, c, ppc, scale, shift, mask_nc, relu);
     RUNET_CHECK_LAUNCH();
 }
 
@@ -468,8 +499,12 @@ extern "C" int runet_bn_bwd_apply(const float* dy, int lddy, const float* x, int
     REQ_VEC(c);
     hipStream_t st = (hipStream_t)stream;
     const float inv_m = 1.0f / (float)(m_total > 0 ? m_total : pixels);
-    if (c % 4 == 0) hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3(ew_grid(pixels * (c / 4))), dim3(TPB), 0, st, dy, lddy, x, ldx, act, ldact, dx, lddx, pixels, hw, c, mean, invstd, scale, sums, mask_nc, inv_m);
-    else hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3(ew_grid(pixels * c)), dim3(TPB), 0, st, dy, lddy, x, ldx, act, ldact, dx, lddx, pixels, hw, c, mean, invstd, scale, sums, mask_nc, inv_m);
+    RUNET_REQUIRE(pixels % hw == 0, "pixels must be a whole number of images");
+    const int nimg = (int)(pixels / hw), vec = (c % 4 == 0) ? 4 : 1;
+    int ppc;
+    const int chunks = stream_chunks(nimg, hw, c, TPB / (c / vec), ppc);
+    if (vec == 4) hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3(chunks, nimg), dim3(TPB), 0, st, dy, lddy, x, ldx, act, ldact, dx, lddx, hw, c, ppc, mean, invstd, scale, sums, mask_nc, inv_m);
+    else hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3(chunks, nimg), dim3(TPB), 0, st, dy, lddy, x, ldx, act, ldact, dx, lddx, hw, c, ppc, mean, invstd, scale, sums, mask_nc, inv_m);
     RUNET_CHECK_LAUNCH();
 }
 
