@@ -16,6 +16,7 @@
 // Algorithmic FLOPs are counted as the direct convolution's (2*9*Cin*Cout per pixel); the MFMA work is 16/36 of that.
 #include "runet_common.h"
 #include "../../include/runet_hip.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -33,54 +34,72 @@ struct WinoArgs {
 constexpr int WT = 32;            // tiles per block
 constexpr int WBN = 64;           // output channels per block
 constexpr int VLD = 20;           // padded k-stride of a V row (conflict-free ds_read_b128)
+constexpr int RH = 10, RW = 18;   // input halo of a 4x8 patch of 2x2 tiles
+constexpr int RPS = 24;           // floats per halo pixel in LDS (16 channels + pad: conflict-free ds_read_b64 in the transform)
 
+template <int ABL>
 __global__ __launch_bounds__(256, 2) void wino_conv_kernel(WinoArgs g) {
-    __shared__ __attribute__((aligned(16))) float V[16 * WT * VLD];     // 40 KB; reused as M[16][32][16] in the epilogue
+    __shared__ __attribute__((aligned(16))) float V[16 * WT * VLD];       // 40 KB; reused as M[16][32][16] in the epilogue
+    __shared__ __attribute__((aligned(16))) float R[RH * RW * RPS];       // 17 KB raw input halo of the current 16-channel chunk
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform: U offsets stay in SGPRs
     const int li = lane & 31, lh = lane >> 5;
-    const long t0 = (long)blockIdx.x * WT;
     const int n0 = blockIdx.y * WBN;
+
+    // block -> (image, 4x8 patch of tiles): 8x16 output pixels, 10x18 input halo shared by the 32 tiles through LDS
+    const int bxs = (g.TX + 7) >> 3, bys = (g.TY + 3) >> 2;
+    const int bimg = blockIdx.x / (bxs * bys);
+    const int brem = blockIdx.x - bimg * (bxs * bys);
+    const int by = brem / bxs, bx = brem - by * bxs;
+    const int h00 = 8 * by - 1, w00 = 16 * bx - 1;                // image coordinates of halo pixel (0,0)
 
     // Every global read is UNCONDITIONAL (a masked lane reads element 0 and the value is then zeroed): no branches around
     // loads, so the compiler's vmcnt bookkeeping stays exact and the prefetches really overlap the MFMAs.
+    // ---- halo loader: item = (halo pixel, 4-channel group); 180 x 4 = 720 items, 3 per thread ----
+    int hoff[3];                  // element offset (0 when the pixel is outside the image / item is padding)
+    int hlds[3];                  // LDS float index, -1 = no item
+    bool hok[3];
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+        const int item = tid + 256 * v;
+        const int px = item >> 2, c4 = item & 3;
+        const int hy = px / RW, hx = px - hy * RW;
+        const int ih = h00 + hy, iw = w00 + hx;
+        const bool in_tile = px < RH * RW;
+        hok[v] = in_tile && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
+        hoff[v] = hok[v] ? (int)((((long)bimg * g.H + ih) * g.W + iw) * g.ldx) + c4 * 4 : 0;
+        hlds[v] = in_tile ? px * RPS + c4 * 4 : -1;
+    }
+    f32x4 hreg[3];
+    auto load_halo = [&](int c0) {
+        const float* xc = g.x + c0;            // wave-uniform
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+            if constexpr (ABL & 1) hreg[v] = f32x4{(float)c0, 1.f, 2.f, 3.f};
+            else hreg[v] = *reinterpret_cast<const f32x4*>(xc + hoff[v]);
+        }
+    };
+    auto store_halo = [&]() {
+#pragma unroll
+        for (int v = 0; v < 3; ++v)
+            if (hlds[v] >= 0) *reinterpret_cast<f32x4*>(&R[hlds[v]]) = hok[v] ? hreg[v] : f32x4{0.f, 0.f, 0.f, 0.f};
+    };
 
-    // ---- loader role: (tile lt, channel pair k2) ----
+    // ---- transform role: (tile lt, channel pair k2); the wave's 8 tiles are one row of the 4x8 patch ----
     const int lt = tid >> 3, k2 = tid & 7;
-    const long tg = t0 + lt;
-    unsigned vmask = 0;           // bit (a*4+b): patch pixel in bounds
-    int poff[16];                 // element offset of each patch pixel for this lane (0 when masked)
-    {
-        const bool tv = tg < g.tiles;
-        const long tt = tv ? tg : 0;
-        const int per = g.TY * g.TX;
-        const int n = (int)(tt / per);
-        const int rem = (int)(tt - (long)n * per);
-        const int ty = rem / g.TX, tx = rem - ty * g.TX;
-        const int h0 = 2 * ty - 1, w0 = 2 * tx - 1;
-        const int pbase = (int)((((long)n * g.H + h0) * g.W + w0) * g.ldx + 2 * k2);
+    const int rbase = ((2 * (lt >> 3)) * RW + 2 * (lt & 7)) * RPS + 2 * k2;      // halo pixel (0,0) of this tile's 4x4 patch
+    auto transform_store = [&]() {
+        // B^T d B on both channels; V[xi][lt][2*k2 .. 2*k2+1]
+        float2 raw[16], tmp[16];
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const bool ok = tv && (unsigned)(h0 + a) < (unsigned)g.H && (unsigned)(w0 + b) < (unsigned)g.W;
-                poff[a * 4 + b] = ok ? pbase + (a * g.W + b) * g.ldx : 0;
-                if (ok) vmask |= 1u << (a * 4 + b);
-            }
-    }
-
-    float2 raw[16];
-    auto load_patch = [&](int c0) {
-        const float* xc = g.x + c0;            // wave-uniform
+            for (int b = 0; b < 4; ++b) raw[a * 4 + b] = *reinterpret_cast<const float2*>(&R[rbase + (a * RW + b) * RPS]);
+        if constexpr (ABL & 2) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) raw[i] = *reinterpret_cast<const float2*>(xc + poff[i]);
-    };
-    auto transform_store = [&]() {
-        // B^T d B on both channels; V[xi][lt][2*k2 .. 2*k2+1]
-        float2 tmp[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i)
-            if (!(vmask & (1u << i))) raw[i] = make_float2(0.f, 0.f);
+            for (int i = 0; i < 16; ++i) *reinterpret_cast<float2*>(&V[(i * WT + lt) * VLD + 2 * k2]) = raw[i];
+            return;
+        }
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             const float2 d0 = raw[b], d1 = raw[4 + b], d2 = raw[8 + b], d3 = raw[12 + b];
@@ -123,7 +142,10 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel(WinoArgs g) {
         for (int kh = 0; kh < 2; ++kh) {
             const f32x4* up = U4 + ((long)((wid * 4 + xl) * K4 + (c0 >> 2) + kh * 2) * g.N + n0);      // wave-uniform
 #pragma unroll
-            for (int b = 0; b < 2; ++b) bf[kh][b] = up[uoff[b]];
+            for (int b = 0; b < 2; ++b) {
+                if constexpr (ABL & 4) bf[kh][b] = f32x4{1.f, 2.f, 3.f, (float)c0};
+                else bf[kh][b] = up[uoff[b]];
+            }
         }
     };
     auto mma = [&](int xl, const f32x4 (&bf)[2][2]) {
@@ -141,12 +163,13 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel(WinoArgs g) {
     };
 
     const int nchunks = g.K >> 4;
-    load_patch(0);
+    load_halo(0);
     load_u(0, 0, bfa);
     for (int ch = 0; ch < nchunks; ++ch) {
         const int c0 = ch * 16;
         const int cn = (ch + 1 < nchunks) ? c0 + 16 : c0;      // last chunk: harmless re-read, keeps the code branch-free
-        __syncthreads();                       // previous chunk's MFMA reads of V are done
+        store_halo();                          // R was last read before the previous chunk's second barrier
+        __syncthreads();                       // R complete; previous chunk's MFMA reads of V are done
         transform_store();
         __syncthreads();
         // the sched_barriers pin each group of loads in FRONT of the 16 MFMAs it overlaps (the scheduler otherwise sinks the
@@ -155,7 +178,7 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel(WinoArgs g) {
         __builtin_amdgcn_sched_barrier(0);
         mma(0, bfa);                           // its U fragments were requested during the previous chunk
         __builtin_amdgcn_sched_barrier(0);
-        load_patch(cn);                        // next chunk's patch: in flight during the rest of this chunk's MFMAs
+        load_halo(cn);                         // next chunk's halo: in flight during the rest of this chunk's MFMAs
         load_u(2, c0, bfa);
         __builtin_amdgcn_sched_barrier(0);
         mma(1, bfb);
@@ -171,19 +194,19 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel(WinoArgs g) {
     }
 
     // ---- epilogue: exchange the 16 positions through LDS (16 output channels per pass), A^T m A, store ----
+    if constexpr (ABL & 8) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) asm volatile("" :: "v"(acc[i][b]));
+        return;
+    }
     float* M = V;                               // M[xi][t][16]
     const int et = tid >> 3;                    // tile of the two (tile, channel) items this thread finishes
     const int en = (tid & 7) * 2;               // channels en, en+1 of the pass
-    const long etg = t0 + et;
-    int e_n = 0, e_h = 0, e_w = 0;
-    const bool e_ok = etg < g.tiles;
-    if (e_ok) {
-        const int per = g.TY * g.TX;
-        e_n = (int)(etg / per);
-        const int rem = (int)(etg - (long)e_n * per);
-        const int ty = rem / g.TX;
-        e_h = 2 * ty; e_w = 2 * (rem - ty * g.TX);
-    }
+    const int e_ty = 4 * by + (et >> 3), e_tx = 8 * bx + (et & 7);
+    const bool e_ok = e_ty < g.TY && e_tx < g.TX;
+    const int e_n = bimg, e_h = 2 * e_ty, e_w = 2 * e_tx;
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
         __syncthreads();
@@ -483,8 +506,17 @@ extern "C" int runet_wino_conv(const float* x, int ldx, const float* U, const fl
     WinoArgs a{};
     a.x = x; a.ldx = ldx; a.U = U; a.bias = bias; a.y = y; a.ldy = ldy; a.K = k; a.N = n;
     a.Nimg = n_img; a.H = h; a.W = w; a.TY = h / 2; a.TX = w / 2; a.tiles = (long)n_img * a.TY * a.TX; a.accumulate = accumulate;
-    dim3 grid(cdiv(a.tiles, WT), cdiv(n, WBN));
-    hipLaunchKernelGGL(wino_conv_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    dim3 grid(n_img * cdiv(a.TY, 4) * cdiv(a.TX, 8), cdiv(n, WBN));
+    static const int abl = getenv("RUNET_WINO_ABL") ? atoi(getenv("RUNET_WINO_ABL")) : 0;      // timing ablations only (wrong results)
+    switch (abl) {
+    case 1: hipLaunchKernelGGL(wino_conv_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a); break;
+    case 2: hipLaunchKernelGGL(wino_conv_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, a); break;
+    case 4: hipLaunchKernelGGL(wino_conv_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, a); break;
+    case 8: hipLaunchKernelGGL(wino_conv_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, a); break;
+    case 7: hipLaunchKernelGGL(wino_conv_kernel<7>, grid, dim3(256), 0, (hipStream_t)stream, a); break;
+    case 15: hipLaunchKernelGGL(wino_conv_kernel<15>, grid, dim3(256), 0, (hipStream_t)stream, a); break;
+    default: hipLaunchKernelGGL(wino_conv_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    }
     RUNET_CHECK_LAUNCH();
 }
 
