@@ -320,16 +320,26 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(WinoWgradArgs g) {
     const int xt = tid >> 5, xc = tid & 31;            // x loader: (tile, cin)
     const bool xc_ok = ci0 + xc < g.cin;
     float rx[16], ry[2][4];
+    // tile coordinates of this thread's three loader items, advanced incrementally (GT tiles per batch): no divisions in the loop
+    struct TileIt { int n, ty, tx; };
+    auto tile_init = [&](long tg) {
+        TileIt t;
+        const long tt = tg < g.tiles ? tg : g.tiles - 1;
+        t.n = (int)(tt / per);
+        const int rem = (int)(tt - (long)t.n * per);
+        t.ty = rem / g.TX; t.tx = rem - t.ty * g.TX;
+        return t;
+    };
+    auto tile_next = [&](TileIt& t) {
+        t.tx += GT;
+        while (t.tx >= g.TX) { t.tx -= g.TX; if (++t.ty == g.TY) { t.ty = 0; ++t.n; } }
+    };
+    TileIt itx = tile_init(t_begin + xt), ity0 = tile_init(t_begin + (tid >> 6)), ity1 = tile_init(t_begin + ((tid + 256) >> 6));
     auto prefetch = [&](long tb) {
         {   // x patch of tile tb + xt
-            const long tg = tb + xt;
-            const bool tv = tg < t_end && xc_ok;
-            const long tt = tg < g.tiles ? tg : 0;
-            const int n = (int)(tt / per);
-            const int rem = (int)(tt - (long)n * per);
-            const int ty = rem / g.TX, tx = rem - ty * g.TX;
-            const int h0 = 2 * ty - 1, w0 = 2 * tx - 1;
-            const float* base = g.x + (((long)n * g.H + h0) * g.W + w0) * g.ldx + ci0 + xc;
+            const bool tv = tb + xt < t_end && xc_ok;
+            const int h0 = 2 * itx.ty - 1, w0 = 2 * itx.tx - 1;
+            const float* base = g.x + (((long)itx.n * g.H + h0) * g.W + w0) * g.ldx + ci0 + xc;
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -337,22 +347,20 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(WinoWgradArgs g) {
                     const bool ok = tv && (unsigned)(h0 + a) < (unsigned)g.H && (unsigned)(w0 + b) < (unsigned)g.W;
                     rx[a * 4 + b] = ok ? base[a * rowx + b * g.ldx] : 0.f;
                 }
+            tile_next(itx);
         }
 #pragma unroll
         for (int v = 0; v < 2; ++v) {   // dy tiles: items (tile, cout) = tid, tid + 256
             const int idx = tid + 256 * v;
             const int yt = idx >> 6, yc = idx & 63;
-            const long tg = tb + yt;
-            const bool tv = tg < t_end && co0 + yc < g.cout;
-            const long tt = tg < g.tiles ? tg : 0;
-            const int n = (int)(tt / per);
-            const int rem = (int)(tt - (long)n * per);
-            const int ty = rem / g.TX, tx = rem - ty * g.TX;
-            const float* base = g.dy + (((long)n * g.H + 2 * ty) * g.W + 2 * tx) * g.ldy + co0 + yc;
+            TileIt& it = v ? ity1 : ity0;
+            const bool tv = tb + yt < t_end && co0 + yc < g.cout;
+            const float* base = g.dy + (((long)it.n * g.H + 2 * it.ty) * g.W + 2 * it.tx) * g.ldy + co0 + yc;
             ry[v][0] = tv ? base[0] : 0.f;
             ry[v][1] = tv ? base[g.ldy] : 0.f;
             ry[v][2] = tv ? base[rowy] : 0.f;
             ry[v][3] = tv ? base[rowy + g.ldy] : 0.f;
+            tile_next(it);
         }
     };
     auto transform_store = [&]() {
