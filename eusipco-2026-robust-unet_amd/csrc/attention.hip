@@ -311,14 +311,15 @@ __global__ void rb_bwd2_final(const float* __restrict__ part, int N, int C, int 
     sdu[i] = (float)a; sdut[i] = (float)b;
 }
 
-// ---- channel-attention backward, per image (grid N): MLP backward, davg/dmx, per-image weight-grad partials
+// ---- channel-attention backward, phase 1, per image (grid N): dz, the MLP's hidden gradients, davg/dmx.
+// Stores the small per-image vectors (dz[C], dpa/dpm/hs[Cr]) that phase 2 turns into the weight gradients.
 __global__ __launch_bounds__(TPB) void ca_bwd_image_kernel(const float* __restrict__ sdu, const float* __restrict__ sdut,
                                                            const float* __restrict__ s2, const float* __restrict__ h2,
                                                            const float* __restrict__ ca, const float* __restrict__ avg,
                                                            const float* __restrict__ mxv, const float* __restrict__ W0p,
                                                            const float* __restrict__ W2p, int C, int Cr,
                                                            float* __restrict__ davg, float* __restrict__ dmx,
-                                                           float* __restrict__ dW0_part, float* __restrict__ dW2_part) {
+                                                           float* __restrict__ dz_out, float* __restrict__ hvec) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* dz = sm;               // [C]
     float* hid = sm + C;          // [2*Cr] pre-activations pa, pm
@@ -330,6 +331,7 @@ __global__ __launch_bounds__(TPB) void ca_bwd_image_kernel(const float* __restri
         const float k = ca[n * C + c];
         const float dca = s2[c] * sdut[n * C + c] + h2[c] * sdu[n * C + c];
         dz[c] = dca * k * (1.f - k);
+        dz_out[n * C + c] = dz[c];
     }
     for (int o = wid; o < 2 * Cr; o += TPB / 64) {
         const int j = o % Cr;
@@ -347,30 +349,44 @@ __global__ __launch_bounds__(TPB) void ca_bwd_image_kernel(const float* __restri
         if (lane == 0) dh[j] = acc;
     }
     __syncthreads();
+    for (int j = tid; j < Cr; j += TPB) {   // hvec[n] = (dpa | dpm | relu(pa)+relu(pm))
+        hvec[((long)n * 3 + 0) * Cr + j] = hid[j] > 0.f ? dh[j] : 0.f;
+        hvec[((long)n * 3 + 1) * Cr + j] = hid[Cr + j] > 0.f ? dh[j] : 0.f;
+        hvec[((long)n * 3 + 2) * Cr + j] = fmaxf(hid[j], 0.f) + fmaxf(hid[Cr + j], 0.f);
+    }
     for (int c = tid; c < C; c += TPB) {
         float da = 0.f, dm = 0.f;
         for (int j = 0; j < Cr; ++j) {
-            const float dpa = hid[j] > 0.f ? dh[j] : 0.f, dpm = hid[Cr + j] > 0.f ? dh[j] : 0.f;
             const float w0 = W0p[c * Cr + j];
-            da += w0 * dpa; dm += w0 * dpm;
-            dW0_part[((long)n * C + c) * Cr + j] = dpa * avg_n[c] + dpm * mx_n[c];
-            dW2_part[((long)n * Cr + j) * C + c] = dz[c] * (fmaxf(hid[j], 0.f) + fmaxf(hid[Cr + j], 0.f));
+            da += w0 * (hid[j] > 0.f ? dh[j] : 0.f);
+            dm += w0 * (hid[Cr + j] > 0.f ? dh[j] : 0.f);
         }
         davg[n * C + c] = da; dmx[n * C + c] = dm;
     }
 }
-// sums over images: weight grads and the bn2 backward sums (sum du0, sum du0*xhat)
+// phase 2 (grid over C*Cr): weight gradients summed over images in image order, and the bn2 backward sums
 __global__ void ca_bwd_final_kernel(const float* __restrict__ sdu, const float* __restrict__ sdut, const float* __restrict__ ca,
                                     const float* __restrict__ davg, const float* __restrict__ dmx, const float* __restrict__ mean_nc,
                                     const float* __restrict__ tval, const float* __restrict__ mean2, const float* __restrict__ invstd2,
-                                    const float* __restrict__ dW0_part, const float* __restrict__ dW2_part, int N, int C, int Cr,
+                                    const float* __restrict__ avg, const float* __restrict__ mxv, const float* __restrict__ dz,
+                                    const float* __restrict__ hvec, int N, int C, int Cr,
                                     float* __restrict__ sums2, float* __restrict__ dW0, float* __restrict__ dW2) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int nw = C * Cr;
     if (i < nw) {
-        double a = 0, b = 0;
-        for (int n = 0; n < N; ++n) { a += dW0_part[(long)n * nw + i]; b += dW2_part[(long)n * nw + i]; }
-        dW0[i] = (float)a; dW2[i] = (float)b;
+        {   // dW0p[c][j] = sum_n dpa[n][j]*avg[n][c] + dpm[n][j]*mx[n][c]
+            const int c = i / Cr, j = i - c * Cr;
+            float a = 0.f;
+            for (int n = 0; n < N; ++n)
+                a += hvec[((long)n * 3 + 0) * Cr + j] * avg[(long)n * C + c] + hvec[((long)n * 3 + 1) * Cr + j] * mxv[(long)n * C + c];
+            dW0[i] = a;
+        }
+        {   // dW2p[j][c] = sum_n dz[n][c] * hs[n][j]
+            const int j = i / C, c = i - j * C;
+            float b = 0.f;
+            for (int n = 0; n < N; ++n) b += dz[(long)n * C + c] * hvec[((long)n * 3 + 2) * Cr + j];
+            dW2[i] = b;
+        }
     }
     if (i < C) {
         const double mu = mean2[i], is = invstd2[i];
@@ -697,7 +713,7 @@ extern "C" int runet_rb_bwd2(const float* dv, int lddv, const float* t2, int ld,
     RUNET_CHECK_LAUNCH();
 }
 
-extern "C" long runet_ca_bwd_workspace_floats(int n_img, int c, int cr) { return 2L * n_img * c * cr; }
+extern "C" long runet_ca_bwd_workspace_floats(int n_img, int c, int cr) { return (long)n_img * (c + 3L * cr) + 64; }
 
 extern "C" int runet_ca_bwd(const float* sdu, const float* sdut, const float* s2, const float* h2, const float* ca, const float* avg,
                             const float* mx, const float* w0p, const float* w2p, const float* mean_nc, const float* tval,
@@ -707,13 +723,13 @@ extern "C" int runet_ca_bwd(const float* sdu, const float* sdut, const float* s2
                   sums2 && dw0p && dw2p, "null pointer");
     REQ_C4(c);
     hipStream_t st = (hipStream_t)stream;
-    float* p0 = workspace;
-    float* p2 = workspace + (long)n_img * c * cr;
+    float* dz = workspace;                              // [n_img][c]
+    float* hvec = workspace + (long)n_img * c;          // [n_img][3][cr]
     const size_t lds = (c + 3 * cr) * sizeof(float);
-    hipLaunchKernelGGL(ca_bwd_image_kernel, dim3(n_img), dim3(TPB), lds, st, sdu, sdut, s2, h2, ca, avg, mx, w0p, w2p, c, cr, davg, dmx, p0, p2);
+    hipLaunchKernelGGL(ca_bwd_image_kernel, dim3(n_img), dim3(TPB), lds, st, sdu, sdut, s2, h2, ca, avg, mx, w0p, w2p, c, cr, davg, dmx, dz, hvec);
     const int tot = c * cr > c ? c * cr : c;
-    hipLaunchKernelGGL(ca_bwd_final_kernel, dim3(cdiv(tot, 128)), dim3(128), 0, st, sdu, sdut, ca, davg, dmx, mean_nc, tval, mean2, invstd2, p0, p2,
-                       n_img, c, cr, sums2, dw0p, dw2p);
+    hipLaunchKernelGGL(ca_bwd_final_kernel, dim3(cdiv(tot, 128)), dim3(128), 0, st, sdu, sdut, ca, davg, dmx, mean_nc, tval, mean2, invstd2, avg, mx,
+                       dz, hvec, n_img, c, cr, sums2, dw0p, dw2p);
     RUNET_CHECK_LAUNCH();
 }
 

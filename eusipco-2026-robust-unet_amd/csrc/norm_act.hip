@@ -114,31 +114,57 @@ __global__ __launch_bounds__(TPB) void chan_stats_partial(const float* __restric
     }
 }
 
-// one thread per (n, c): combine the chunks of image n
+// block = CW channels x (256/CW) chunk-lanes of ONE image: each thread Chan-combines its share of the chunks (in chunk order,
+// so strict comparisons keep the first occurrence of max/min), lane 0 of each channel combines the lanes in lane order
 template <bool MINMAX>
-__global__ void chan_stats_combine(const float* __restrict__ part, int N, int C, int nchunks, float* __restrict__ mean_nc,
-                                   float* __restrict__ m2_nc, float* __restrict__ max_nc, float* __restrict__ min_nc,
-                                   int* __restrict__ imax_nc, int* __restrict__ imin_nc) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N * C) return;
-    const int n = i / C, c = i - n * C;
+__global__ __launch_bounds__(TPB) void chan_stats_combine(const float* __restrict__ part, int C, int nchunks, int CW,
+                                                          float* __restrict__ mean_nc, float* __restrict__ m2_nc,
+                                                          float* __restrict__ max_nc, float* __restrict__ min_nc,
+                                                          int* __restrict__ imax_nc, int* __restrict__ imin_nc) {
+    __shared__ double sd[3][TPB];
+    __shared__ float sf[2][TPB];
+    __shared__ int si[2][TPB];
     constexpr int S = MINMAX ? 7 : 3;
+    const int PL = TPB / CW;
+    const int cl = threadIdx.x % CW, pl = threadIdx.x / CW;
+    const int c = blockIdx.x * CW + cl, n = blockIdx.y;
     double n_ = 0, mean = 0, m2 = 0;
     float bmx = -FLT_MAX, bmn = FLT_MAX;
-    int bimx = 0, bimn = 0;
-    for (int k = 0; k < nchunks; ++k) {
-        const float* o = part + (((long)n * nchunks + k) * C + c) * S;
-        chan_combine(n_, mean, m2, o[0], o[1], o[2]);
-        if constexpr (MINMAX) {
-            if (o[0] > 0.f) {   // chunks are in pixel order: strict comparisons keep the first occurrence
-                if (o[3] > bmx) { bmx = o[3]; bimx = __float_as_int(o[5]); }
-                if (o[4] < bmn) { bmn = o[4]; bimn = __float_as_int(o[6]); }
+    int bimx = 0x7fffffff, bimn = 0x7fffffff;
+    if (c < C && pl < PL) {
+        // contiguous share of the chunk list per lane keeps pixel order: lane pl owns chunks [k0, k1)
+        const int per = (nchunks + PL - 1) / PL;
+        const int k0 = pl * per, k1 = min(nchunks, k0 + per);
+        for (int k = k0; k < k1; ++k) {
+            const float* o = part + (((long)n * nchunks + k) * C + c) * S;
+            chan_combine(n_, mean, m2, o[0], o[1], o[2]);
+            if constexpr (MINMAX) {
+                if (o[0] > 0.f) {
+                    if (o[3] > bmx) { bmx = o[3]; bimx = __float_as_int(o[5]); }
+                    if (o[4] < bmn) { bmn = o[4]; bimn = __float_as_int(o[6]); }
+                }
             }
         }
     }
-    mean_nc[i] = (float)mean;
-    m2_nc[i] = (float)m2;
-    if constexpr (MINMAX) { max_nc[i] = bmx; min_nc[i] = bmn; imax_nc[i] = bimx; imin_nc[i] = bimn; }
+    sd[0][threadIdx.x] = n_; sd[1][threadIdx.x] = mean; sd[2][threadIdx.x] = m2;
+    if constexpr (MINMAX) { sf[0][threadIdx.x] = bmx; sf[1][threadIdx.x] = bmn; si[0][threadIdx.x] = bimx; si[1][threadIdx.x] = bimn; }
+    __syncthreads();
+    if (pl == 0 && c < C) {
+        for (int j = 1; j < PL; ++j) {
+            const int t = j * CW + cl;
+            chan_combine(n_, mean, m2, sd[0][t], sd[1][t], sd[2][t]);
+            if constexpr (MINMAX) {
+                if (sd[0][t] > 0.0) {
+                    if (sf[0][t] > bmx) { bmx = sf[0][t]; bimx = si[0][t]; }
+                    if (sf[1][t] < bmn) { bmn = sf[1][t]; bimn = si[1][t]; }
+                }
+            }
+        }
+        const int i = n * C + c;
+        mean_nc[i] = (float)mean;
+        m2_nc[i] = (float)m2;
+        if constexpr (MINMAX) { max_nc[i] = bmx; min_nc[i] = bmn; imax_nc[i] = bimx; imin_nc[i] = bimn; }
+    }
 }
 
 __global__ void bn_finalize_kernel(const float* __restrict__ mean_nc, const float* __restrict__ m2_nc, int N, int C, long HW,
@@ -381,7 +407,7 @@ __global__ __launch_bounds__(TPB) void chan_sum_final(const float* __restrict__ 
     }
 }
 
-inline int final_cw(int c) { return c >= 32 ? 32 : c; }
+inline int final_cw(int c, long nparts = 0) { const int w = nparts >= 256 ? 4 : 32; return c >= w ? w : c; }
 
 inline int pick_chunks(int N, int HW, int C, int rows) {
     // ~32 vector loads per thread; at least one pass of `rows` pixels per chunk
@@ -441,11 +467,12 @@ extern "C" int runet_chan_stats(const float* x, int ld, int n_img, int hw, int c
     if (vec == 4) { if (want_minmax) LAUNCH_STATS(4, true); else LAUNCH_STATS(4, false); }
     else { if (want_minmax) LAUNCH_STATS(1, true); else LAUNCH_STATS(1, false); }
 #undef LAUNCH_STATS
-    const int tot = n_img * c;
+    const int ccw = chunks >= 16 ? (c >= 8 ? 8 : c) : (c >= 64 ? 64 : c);
+    dim3 cgrid(cdiv(c, ccw), n_img);
     if (want_minmax)
-        hipLaunchKernelGGL((chan_stats_combine<true>), dim3(cdiv(tot, 128)), dim3(128), 0, st, workspace, n_img, c, chunks, mean_nc, m2_nc, max_nc, min_nc, imax_nc, imin_nc);
+        hipLaunchKernelGGL((chan_stats_combine<true>), cgrid, dim3(TPB), 0, st, workspace, c, chunks, ccw, mean_nc, m2_nc, max_nc, min_nc, imax_nc, imin_nc);
     else
-        hipLaunchKernelGGL((chan_stats_combine<false>), dim3(cdiv(tot, 128)), dim3(128), 0, st, workspace, n_img, c, chunks, mean_nc, m2_nc, nullptr, nullptr, nullptr, nullptr);
+        hipLaunchKernelGGL((chan_stats_combine<false>), cgrid, dim3(TPB), 0, st, workspace, c, chunks, ccw, mean_nc, m2_nc, nullptr, nullptr, nullptr, nullptr);
     RUNET_CHECK_LAUNCH();
 }
 
@@ -488,7 +515,8 @@ extern "C" int runet_bn_bwd_reduce(const float* dy, int lddy, const float* x, in
     dim3 grid(chunks, n_img);
     if (vec == 4) hipLaunchKernelGGL((bn_bwd_reduce_partial<4>), grid, dim3(TPB), lds, st, dy, lddy, x, ldx, act, ldact, hw, c, mean, invstd, mask_nc, ppc, workspace);
     else hipLaunchKernelGGL((bn_bwd_reduce_partial<1>), grid, dim3(TPB), lds, st, dy, lddy, x, ldx, act, ldact, hw, c, mean, invstd, mask_nc, ppc, workspace);
-    hipLaunchKernelGGL(bn_bwd_reduce_final, dim3(cdiv(c, final_cw(c))), dim3(TPB), 0, st, workspace, chunks * n_img, c, final_cw(c), sums);
+    const int cw = final_cw(c, (long)chunks * n_img);
+    hipLaunchKernelGGL(bn_bwd_reduce_final, dim3(cdiv(c, cw)), dim3(TPB), 0, st, workspace, chunks * n_img, c, cw, sums);
     RUNET_CHECK_LAUNCH();
 }
 
@@ -521,6 +549,7 @@ extern "C" int runet_chan_sum(const float* x, int ld, long pixels, int c, float*
     const size_t lds = (size_t)rows * c * sizeof(float);
     if (vec == 4) hipLaunchKernelGGL((chan_sum_partial<4>), dim3((int)chunks), dim3(TPB), lds, st, x, ld, pixels, c, ppc, workspace);
     else hipLaunchKernelGGL((chan_sum_partial<1>), dim3((int)chunks), dim3(TPB), lds, st, x, ld, pixels, c, ppc, workspace);
-    hipLaunchKernelGGL(chan_sum_final, dim3(cdiv(c, final_cw(c))), dim3(TPB), 0, st, workspace, (int)chunks, c, final_cw(c), out, accumulate);
+    const int cw = final_cw(c, chunks);
+    hipLaunchKernelGGL(chan_sum_final, dim3(cdiv(c, cw)), dim3(TPB), 0, st, workspace, (int)chunks, c, cw, out, accumulate);
     RUNET_CHECK_LAUNCH();
 }
