@@ -164,15 +164,24 @@ def conv_wgrad(x, dy, kh, kw, cin_w=None, dil=1, out=None):
     cin_w = cin if cin_w is None else cin_w
     if out is None:
         out = torch.empty((kh, kw, cin_w, cout), device=x.device, dtype=torch.float32)
+    prof = _PROFILE is not None
+    if prof:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     if USE_WINOGRAD and kh == 3 and dil == 1 and cin_w == cin and h % 2 == 0 and w % 2 == 0 and cin >= 16:
+        name = "wino_wgrad_kernel(+reduce)"
         nws = lib.runet_wino_wgrad_workspace_floats(n, h, w, cin, cout)
         ws = workspace(nws, x.device)
         check(lib.runet_wino_wgrad(x.data_ptr(), ld(x), dy.data_ptr(), ld(dy), out.data_ptr(), ws.data_ptr(), ws.numel(), n, h, w, cin, cout, stream()))
-        return out
-    nws = lib.runet_conv_wgrad_workspace_floats(n, h, w, cin_w, cout, kh, kw)
-    ws = workspace(nws, x.device)
-    check(lib.runet_conv_wgrad(x.data_ptr(), ld(x), dy.data_ptr(), ld(dy), out.data_ptr(), ws.data_ptr(), ws.numel(),
-                               n, h, w, cin, cin_w, cout, kh, kw, dil, 0, stream()))
+    else:
+        name = "wgrad_tile_kernel/wgrad_kernel(+reduce)"
+        nws = lib.runet_conv_wgrad_workspace_floats(n, h, w, cin_w, cout, kh, kw)
+        ws = workspace(nws, x.device)
+        check(lib.runet_conv_wgrad(x.data_ptr(), ld(x), dy.data_ptr(), ld(dy), out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                   n, h, w, cin, cin_w, cout, kh, kw, dil, 0, stream()))
+    if prof:
+        e1.record()
+        _PROFILE.append((name, 2.0 * n * h * w * kh * kw * cin_w * cout, e0, e1))
     return out
 
 
