@@ -224,25 +224,33 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IGemmArgs g) {
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const long p = m0 + wm0 + a * 32 + row;
-            if (p < P) {
-                long op = p;
+        for (int half = 0; half < 2; ++half) {
+            // accumulate mode: the old values of 8 rows are all requested before the first add, so the loads overlap
+            // instead of one load -> wait -> store per element (8 at a time keeps the register count where it was)
+            float* drow[8];
+            float old[8][TN];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int r = half * 8 + i;
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const long p = m0 + wm0 + a * 32 + row;
+                long op = p < P ? p : 0;
                 if (!same_pix) {
-                    const int nimg = (int)(p / HW);
-                    const int rem = (int)(p - (long)nimg * HW);
+                    const int nimg = (int)(op / HW);
+                    const int rem = (int)(op - (long)nimg * HW);
                     const int h = rem / g.W, w = rem - h * g.W;
                     op = ((long)nimg * g.Hout + (h * g.o_scale + o_dh)) * g.Wout + (w * g.o_scale + o_dw);
                 }
-                float* drow = g.y + op * g.ldy;
+                drow[i] = p < P ? g.y + op * g.ldy : nullptr;
 #pragma unroll
-                for (int b = 0; b < TN; ++b) {
-                    if (ncol[b] < g.Ncols) {
-                        float v = acc[a][b][r] + bv[b];
-                        if (g.accumulate) v += drow[ncol[b]];
-                        drow[ncol[b]] = v;
-                    }
+                for (int b = 0; b < TN; ++b) old[i][b] = (g.accumulate && drow[i] && ncol[b] < g.Ncols) ? drow[i][ncol[b]] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (drow[i]) {
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+                        if (ncol[b] < g.Ncols) drow[i][ncol[b]] = acc[a][b][half * 8 + i] + bv[b] + old[i][b];
                 }
             }
         }
