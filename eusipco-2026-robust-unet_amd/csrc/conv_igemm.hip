@@ -411,6 +411,7 @@ struct WGradTileArgs {
     int Kci, Kvalid, Nco;
     int Nimg, H, W;
     int tiles_h, tiles_w, total_tiles, tiles_per_split, co_chunks;
+    int dy_up;                  // 1: transposed conv (KS == 1 only): dy pixel of x pixel (h, w) is (2h + z/2, 2w + z%2), z = blockIdx.z
 };
 
 template <int KS, int TM, int TN>
@@ -476,7 +477,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(WGradTileArgs g) {
                             val = *reinterpret_cast<const f32x4*>(g.dy + (((long)n * g.H + oh) * g.W + ow) * g.ldy + co0 + cq * 4);
                     } else {
                         const long p = (long)t * NPX + px;
-                        if (p < P) val = *reinterpret_cast<const f32x4*>(g.dy + p * g.ldy + co0 + cq * 4);
+                        if (p < P) {
+                            long q = p;
+                            if (g.dy_up) {
+                                const int hw = g.H * g.W;
+                                const int ni = (int)(p / hw);
+                                const int rem = (int)(p - (long)ni * hw);
+                                const int hh = rem / g.W, ww = rem - hh * g.W;
+                                q = ((long)ni * 2 * g.H + 2 * hh + (blockIdx.z >> 1)) * (2 * g.W) + 2 * ww + (blockIdx.z & 1);
+                            }
+                            val = *reinterpret_cast<const f32x4*>(g.dy + q * g.ldy + co0 + cq * 4);
+                        }
                     }
                 }
             }
@@ -537,7 +548,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(WGradTileArgs g) {
 
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        float* slab = g.out + ((long)blockIdx.y * NT + t) * g.Kvalid * g.Nco;
+        float* slab = g.out + (((long)blockIdx.y * gridDim.z + blockIdx.z) * NT + t) * g.Kvalid * g.Nco;
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
             const int co = co0 + (wc * TN + b) * 32 + li;
@@ -575,7 +586,67 @@ template <int KS, int TM, int TN>
 static void launch_wgrad_tile(const WGradTileArgs& a, const TilePlan& p, hipStream_t st) {
     constexpr int HALO = (KS == 3) ? 1 : 0;
     const size_t lds = ((size_t)(16 + 2 * HALO) * (4 + 2 * HALO) * 64 * TM + 64 * 64 * TN) * sizeof(float);
-    hipLaunchKernelGGL((wgrad_tile_kernel<KS, TM, TN>), dim3(p.ci_chunks * p.co_chunks, p.splits), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((wgrad_tile_kernel<KS, TM, TN>), dim3(p.ci_chunks * p.co_chunks, p.splits, a.dy_up ? 4 : 1), dim3(256), lds, st, a);
+}
+
+
+// ------------------------------------------------------------------------------------------ wgrad of the RGB stem (cin <= 4)
+// dW[3][3][cin_w][cout] = sum_p x4[p + tap][0:cin_w] * dy[p][co].  A 27-deep "GEMM" wastes the matrix cores (the tile kernel pads
+// cin to 64), and the op is bound by reading dy once, so this is a plain VALU kernel: a thread owns 4 output channels and every
+// 16th pixel of a strip of image rows, keeps the 9 x 4 x 4 partial products in registers, the block reduces them through LDS and
+// writes one partial slab; slab_reduce_kernel sums the slabs.
+constexpr int STEM_ROWS = 4;     // image rows per block
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dy, int ldy,
+                                                         float* __restrict__ slabs, int H, int W, int cin_w, int cout) {
+    __shared__ float red[256 * 16];                       // one tap at a time: [thread][ci 0..3][co 0..3]
+    const int cq = cout / 4;                              // column threads
+    const int rows = 256 / cq;                            // pixel lanes
+    const int tid = threadIdx.x, col = tid % cq, pl = tid / cq;
+    const int n = blockIdx.y, r0 = blockIdx.x * STEM_ROWS;
+    const int npx = min(STEM_ROWS, H - r0) * W;
+    float acc[9][4][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[t][c][q] = 0.f;
+    if (pl < rows) {
+        for (int i = pl; i < npx; i += rows) {
+            const int h = r0 + i / W, w = i % W;
+            const f32x4 g = *reinterpret_cast<const f32x4*>(dy + (((long)n * H + h) * W + w) * ldy + col * 4);
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int s2 = 0; s2 < 3; ++s2) {
+                    const int ih = h + r - 1, iw = w + s2 - 1;
+                    f32x4 xv = {0.f, 0.f, 0.f, 0.f};
+                    if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
+                        xv = *reinterpret_cast<const f32x4*>(x + (((long)n * H + ih) * W + iw) * ldx);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc[r * 3 + s2][c][q] += xv[c] * g[q];
+                }
+        }
+    }
+    float* slab = slabs + ((long)blockIdx.y * gridDim.x + blockIdx.x) * 9 * cin_w * cout;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) red[tid * 16 + c * 4 + q] = (pl < rows) ? acc[t][c][q] : 0.f;
+        __syncthreads();
+        // 16*cq outputs of this tap: (ci, co) = (c, col*4+q); thread u sums over the pixel lanes
+        for (int u = tid; u < 16 * cq; u += 256) {
+            const int cc = u / 16, e = u % 16, c = e >> 2, q = e & 3;
+            float sacc = 0.f;
+            for (int p = 0; p < rows; ++p) sacc += red[(p * cq + cc) * 16 + e];
+            if (c < cin_w) slab[((long)t * cin_w + c) * cout + cc * 4 + q] = sacc;
+        }
+    }
 }
 
 // out[i] = sum_k slabs[k][i]: block = 32 float4 columns x 8 split-lanes (fixed summation order: reproducible)
@@ -716,12 +787,15 @@ static void wgrad_plan(long P, int cin_w, int cout, int ntaps, bool& big, int& t
 }
 
 static bool use_tile_kernel(int kh, int kw, int dil, int transposed) {
-    return !transposed && ((kh == 1 && kw == 1) || (kh == 3 && kw == 3 && dil == 1));
+    if (transposed) return kh == 2 && kw == 2;
+    return (kh == 1 && kw == 1) || (kh == 3 && kw == 3 && dil == 1);
 }
 
 extern "C" long runet_conv_wgrad_workspace_floats(int n_img, int h, int w_, int cin_w, int cout, int kh, int kw) {
-    if (kh == kw && (kh == 1 || kh == 3)) {       // dilation unknown here: take the larger of the two plans
-        const TilePlan p = wgrad_tile_plan(n_img, h, w_, cin_w, cout, kh);
+    if (kh == 3 && kw == 3 && cin_w <= 4) return (long)cdiv(h, 4) * n_img * 9 * cin_w * cout + 64L * 9 * cin_w * cout;   // stem kernel slabs
+    if (kh == kw && (kh == 1 || kh == 3 || kh == 2)) {       // dilation unknown here: take the larger of the two plans
+        TilePlan p = wgrad_tile_plan(n_img, h, w_, cin_w, cout, kh == 2 ? 1 : kh);
+        if (kh == 2) { p.splits = cdiv(p.splits, 4); p.tps = cdiv(p.total_tiles, p.splits); p.splits = cdiv(p.total_tiles, p.tps); }
         bool big; int tiles, splits;
         wgrad_plan((long)n_img * h * w_, cin_w, cout, kh * kw, big, tiles, splits);
         const long a = p.splits > 1 ? (long)p.splits * kh * kw * cin_w * cout : 0;
@@ -743,8 +817,17 @@ extern "C" int runet_conv_wgrad(const float* x, int ldx, const float* dy, int ld
     RUNET_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0 && ((uintptr_t)dw % 16) == 0, "pointers must be 16-byte aligned");
     RUNET_REQUIRE((kh == 1 && kw == 1) || (kh == 3 && kw == 3) || (kh == 2 && kw == 2 && transposed), "unsupported kernel size");
     hipStream_t st = (hipStream_t)stream;
+    if (!transposed && kh == 3 && kw == 3 && dil == 1 && cin == 4 && cout <= 1024 && 256 % (cout / 4) == 0) {      // RGB stem
+        const int nblk = cdiv(h, STEM_ROWS) * n_img;
+        const long wsize = 9L * cin_w * cout;
+        RUNET_REQUIRE(workspace && workspace_floats >= nblk * wsize, "workspace too small for the stem weight gradient");
+        hipLaunchKernelGGL(stem_wgrad_kernel, dim3(cdiv(h, STEM_ROWS), n_img), dim3(256), 0, st, x, ldx, dy, ldy, workspace, h, w_, cin_w, cout);
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(wsize, 32 * 4)), dim3(256), 0, st, workspace, dw, wsize, nblk);
+        RUNET_CHECK_LAUNCH();
+    }
     if (use_tile_kernel(kh, kw, dil, transposed)) {
-        TilePlan p = wgrad_tile_plan(n_img, h, w_, cin_w, cout, kh);
+        TilePlan p = wgrad_tile_plan(n_img, h, w_, cin_w, cout, transposed ? 1 : kh);
+        if (transposed) { p.splits = cdiv(p.splits, 4); p.tps = cdiv(p.total_tiles, p.splits); p.splits = cdiv(p.total_tiles, p.tps); }   // 4 taps ride on grid.z
         const long wsize = (long)kh * kw * cin_w * cout;
         if (p.splits > 1 && (workspace == nullptr || workspace_floats < p.splits * wsize)) {
             int s2 = workspace ? (int)(workspace_floats / wsize) : 1;
@@ -756,6 +839,7 @@ extern "C" int runet_conv_wgrad(const float* x, int ldx, const float* dy, int ld
         t.x = x; t.ldx = ldx; t.dy = dy; t.ldy = ldy; t.out = (p.splits > 1) ? workspace : dw;
         t.Kci = cin; t.Kvalid = cin_w; t.Nco = cout; t.Nimg = n_img; t.H = h; t.W = w_;
         t.tiles_h = p.tiles_h; t.tiles_w = p.tiles_w; t.total_tiles = p.total_tiles; t.tiles_per_split = p.tps; t.co_chunks = p.co_chunks;
+        t.dy_up = transposed ? 1 : 0;
         if (kh == 3) launch_wgrad_tile<3, 1, 1>(t, p, st);
         else if (p.tm == 2 && p.tn == 2) launch_wgrad_tile<1, 2, 2>(t, p, st);
         else if (p.tm == 2) launch_wgrad_tile<1, 2, 1>(t, p, st);
