@@ -17,9 +17,9 @@ import importlib as _il
 _LAZY = {
     "RobustUNet": "model", "ResidualBlock": "model", "DilatedBlock": "model", "AttentionGate": "model",
     "ChannelAttention": "model", "SpatialAttention": "model",
-    "CoastalDataset": "data", "prepare_dataset": "data", "synthetic_batch": "data",
+    "CoastalDataset": "data", "prepare_dataset": "data", "synthetic_batch": "data", "DevicePrefetcher": "data",
     "ModelEvaluator": "evaluator", "FusedAdam": "optim", "bce_loss": "ops", "GradAllReducer": "ddp",
-    "TrainStep": "trainer",
+    "TrainStep": "trainer", "fit": "trainer",
 }
 
 

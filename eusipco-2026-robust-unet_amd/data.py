@@ -114,9 +114,10 @@ class CoastalDataset(Dataset):
             return np.zeros((image_size[1], image_size[0]), dtype=np.uint8)
 
 
-def prepare_dataset(images_dir, labels_dir, batch_size=4, image_size=(512, 512), num_workers=0):
+def prepare_dataset(images_dir, labels_dir, batch_size=4, image_size=(512, 512), num_workers=0, pin_memory=False):
     """Sorted listing, image/JSON pairing by basename, first 80 % train / last 20 % val,
-    train shuffled.  `image_size` / `num_workers` are extensions (reference: 512, 0)."""
+    train shuffled.  `image_size` / `num_workers` / `pin_memory` are extensions (reference: 512, 0, False);
+    with workers + pinned memory + data.DevicePrefetcher the decode/rasterise/resize work leaves the step's critical path."""
     image_files, label_files = [], []
     for img_file in sorted(os.listdir(images_dir)):
         if img_file.lower().endswith((".png", ".jpg", ".jpeg")):
@@ -131,8 +132,9 @@ def prepare_dataset(images_dir, labels_dir, batch_size=4, image_size=(512, 512),
     tf = Compose([Resize(image_size), ToTensor(), Normalize(IMAGENET_MEAN, IMAGENET_STD)])
     train = CoastalDataset(image_files[:split], label_files[:split], transform=tf, image_size=image_size)
     val = CoastalDataset(image_files[split:], label_files[split:], transform=tf, image_size=image_size)
-    return (DataLoader(train, batch_size=batch_size, shuffle=True, num_workers=num_workers),
-            DataLoader(val, batch_size=batch_size, shuffle=False, num_workers=num_workers))
+    kw = dict(num_workers=num_workers, pin_memory=pin_memory, persistent_workers=num_workers > 0)
+    return (DataLoader(train, batch_size=batch_size, shuffle=True, **kw),
+            DataLoader(val, batch_size=batch_size, shuffle=False, **kw))
 
 
 # --------------------------------------------------------------------------- synthetic tiles
@@ -158,3 +160,47 @@ def synthetic_batch(n, size, seed=1234):
     imgs = torch.from_numpy(prng.normal_f32((n, 3, size, size), prng.name_seed("images", seed)))
     masks = np.stack([rasterize_shapes(synthetic_shapes(size, seed * 1000 + i), (size, size)) for i in range(n)])
     return imgs, torch.from_numpy(masks.astype(np.float32)).unsqueeze(1)
+
+
+# --------------------------------------------------------------------------- input pipeline off the critical path
+class DevicePrefetcher:
+    """Iterates a DataLoader one batch ahead: the next (images, masks) pair is copied host->device on a side HIP stream
+    (pinned memory when the loader provides it) while the current step computes.  The reference runs its dataset inline
+    with `num_workers=0` and a blocking `.to(device)` per batch (/root/reference/Main_Final.py:570-571, 708-709); at
+    hundreds of images/s that becomes the bottleneck.  Drop-in: `for images, masks in
+    DevicePrefetcher(loader, device)`.  On a CPU device it degrades to a plain pass-through."""
+
+    def __init__(self, loader, device):
+        self.loader = loader
+        self.device = torch.device(device)
+        self.cuda = self.device.type == "cuda"
+        self.stream = torch.cuda.Stream(device=self.device) if self.cuda else None
+
+    def __len__(self):
+        return len(self.loader)
+
+    def _stage(self, batch):
+        if not self.cuda:
+            return tuple(t.to(self.device) if torch.is_tensor(t) else t for t in batch)
+        with torch.cuda.stream(self.stream):
+            return tuple(t.to(self.device, non_blocking=True) if torch.is_tensor(t) else t for t in batch)
+
+    def __iter__(self):
+        it = iter(self.loader)
+        try:
+            nxt = self._stage(next(it))
+        except StopIteration:
+            return
+        while True:
+            if self.cuda:
+                torch.cuda.current_stream(self.device).wait_stream(self.stream)
+                for t in nxt:
+                    if torch.is_tensor(t):
+                        t.record_stream(torch.cuda.current_stream(self.device))
+            cur = nxt
+            try:
+                nxt = self._stage(next(it))
+            except StopIteration:
+                yield cur
+                return
+            yield cur

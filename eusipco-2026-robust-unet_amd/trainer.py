@@ -24,3 +24,69 @@ class TrainStep:
             self.grad_sync.finish()
         self.optimizer.step()
         return loss
+
+
+def fit(model, train_loader, val_loader, device, epochs=200, lr=1e-4, weight_decay=1e-4, save_dir="./models", lr_patience=10,
+        stop_patience=20, grad_sync=None, log=print):
+    """Checkpointing / early-stopping loop with the behaviour of the reference's older trainer
+    (/root/reference/train_water_segmentation.py:514-645) around the Robust U-Net step:
+    ReduceLROnPlateau(factor 0.5, patience `lr_patience`) stepped on the VALIDATION loss, the state_dict of the best
+    validation IoU saved to `<save_dir>/best_water_segmentation_model.pth`, early stop after `stop_patience` epochs without an
+    IoU improvement.  The checkpoint holds plain contiguous OIHW tensors under the reference's keys, so the reference's
+    `RobustUNet.load_state_dict(torch.load(path))` accepts it.  History keys follow the reference (`train_losses`,
+    `val_losses`, `accuracies`, `iou_scores`, `learning_rates`, `best_model_epoch`, `training_time`); it is written as JSON
+    (the reference pickles it).  Validation IoU / accuracy are the mean of Main_Final.py's per-image metrics."""
+    import json
+    import os
+    import time
+
+    import numpy as np
+    import torch
+
+    from .data import DevicePrefetcher
+    from .evaluator import ModelEvaluator
+
+    os.makedirs(save_dir, exist_ok=True)
+    step = TrainStep(model, lr=lr, weight_decay=weight_decay, grad_sync=grad_sync)
+    sched = torch.optim.lr_scheduler.ReduceLROnPlateau(step.optimizer, mode="min", factor=0.5, patience=lr_patience)
+    ev = ModelEvaluator(device)
+    hist = {"train_losses": [], "val_losses": [], "accuracies": [], "iou_scores": [], "learning_rates": [], "best_model_epoch": 0,
+            "training_time": 0.0}
+    best_iou, waited, t0 = 0.0, 0, time.time()
+    ckpt = os.path.join(save_dir, "best_water_segmentation_model.pth")
+    for epoch in range(epochs):
+        model.train()
+        losses = []
+        for images, masks in DevicePrefetcher(train_loader, device):
+            losses.append(step(images, masks))                 # device scalars: one host sync per epoch, not per step
+        train_loss = float(torch.stack(losses).mean().item())
+        model.eval()
+        vloss, mets = [], []
+        with torch.no_grad():
+            for images, masks in DevicePrefetcher(val_loader, device):
+                prob = model(images)
+                vloss.append(ops.bce_loss(prob, masks))
+                mets += ev.batch_metrics(prob, masks)
+        val_loss = float(torch.stack(vloss).mean().item())
+        iou, acc = float(np.mean([m["iou"] for m in mets])), float(np.mean([m["accuracy"] for m in mets]))
+        sched.step(val_loss)
+        hist["train_losses"].append(train_loss)
+        hist["val_losses"].append(val_loss)
+        hist["accuracies"].append(acc)
+        hist["iou_scores"].append(iou)
+        hist["learning_rates"].append(step.optimizer.param_groups[0]["lr"])
+        if iou > best_iou:
+            best_iou, waited = iou, 0
+            hist["best_model_epoch"] = epoch
+            torch.save({k: v.detach().cpu().contiguous() for k, v in model.state_dict().items()}, ckpt)
+        else:
+            waited += 1
+        log(f"epoch {epoch + 1}/{epochs}: train {train_loss:.4f} val {val_loss:.4f} IoU {iou:.4f} acc {acc:.4f} "
+            f"lr {hist['learning_rates'][-1]:.2e} best IoU {best_iou:.4f} (epoch {hist['best_model_epoch'] + 1})")
+        if waited >= stop_patience:
+            log(f"early stop: {stop_patience} epochs without IoU improvement")
+            break
+    hist["training_time"] = time.time() - t0
+    with open(os.path.join(save_dir, "training_history.json"), "w") as f:
+        json.dump(hist, f)
+    return hist

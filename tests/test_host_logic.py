@@ -127,3 +127,10 @@ def test_synthetic_batch_is_deterministic(pkg):
     b, mb = pkg.synthetic_batch(2, 32, seed=5)
     assert torch.equal(a, b) and torch.equal(ma, mb)
     assert 0.05 < float(ma.mean()) < 0.95
+
+
+def test_device_prefetcher_passthrough_on_cpu(pkg):
+    batches = [(torch.full((2, 3), float(i)), torch.full((2, 1), float(-i))) for i in range(4)]
+    out = list(pkg.DevicePrefetcher(batches, "cpu"))
+    assert len(out) == 4 and all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(out, batches))
+    assert list(pkg.DevicePrefetcher([], "cpu")) == []
