@@ -679,13 +679,14 @@ void launch_igemm(const IGemmArgs& a, int gz, hipStream_t st) {
     hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, KC>), grid, dim3(256), lds, st, a);
 }
 
-enum IGemmVariant { V_128x32 = 0, V_256x64 = 1, V_128x64 = 2, V_128x128 = 3 };
+enum IGemmVariant { V_128x32 = 0, V_256x64 = 1, V_128x64 = 2, V_128x128 = 3, V_64x64 = 4 };
 
 IGemmVariant pick_variant(long P, int ncols) {
     if (ncols <= 32) return V_128x32;
     if (ncols <= 64) return (P >= 256L * 512) ? V_256x64 : V_128x64;
     const long blocks128 = (long)cdiv(P, 128) * cdiv(ncols, 128);
     if (blocks128 >= 512 || (ncols % 128 == 0 && blocks128 >= 256)) return V_128x128;
+    if ((long)cdiv(P, 128) * cdiv(ncols, 64) < 256) return V_64x64;      // few pixels (deep levels): smaller tiles keep every CU busy
     return V_128x64;
 }
 
@@ -696,15 +697,16 @@ void dispatch_igemm(const IGemmArgs& a, int gz, hipStream_t st) {
     case V_256x64: launch_igemm<256, 64, 64, 64, KC>(a, gz, st); break;
     case V_128x64: launch_igemm<128, 64, 64, 32, KC>(a, gz, st); break;
     case V_128x128: launch_igemm<128, 128, 64, 64, KC>(a, gz, st); break;
+    case V_64x64: launch_igemm<64, 64, 32, 32, KC>(a, gz, st); break;
     }
 }
 
 }  // namespace
 
 extern "C" const char* runet_conv_igemm_kernel_name(int n_img, int h, int w_, int cout, int mode) {
-    static const char* names[2][4] = {
-        {"igemm_kernel<128, 32, 32, 32, false>", "igemm_kernel<256, 64, 64, 64, false>", "igemm_kernel<128, 64, 64, 32, false>", "igemm_kernel<128, 128, 64, 64, false>"},
-        {"igemm_kernel<128, 32, 32, 32, true>", "igemm_kernel<256, 64, 64, 64, true>", "igemm_kernel<128, 64, 64, 32, true>", "igemm_kernel<128, 128, 64, 64, true>"}};
+    static const char* names[2][5] = {
+        {"igemm_kernel<128, 32, 32, 32, false>", "igemm_kernel<256, 64, 64, 64, false>", "igemm_kernel<128, 64, 64, 32, false>", "igemm_kernel<128, 128, 64, 64, false>", "igemm_kernel<64, 64, 32, 32, false>"},
+        {"igemm_kernel<128, 32, 32, 32, true>", "igemm_kernel<256, 64, 64, 64, true>", "igemm_kernel<128, 64, 64, 32, true>", "igemm_kernel<128, 128, 64, 64, true>", "igemm_kernel<64, 64, 32, 32, true>"}};
     const bool kc = (mode == RUNET_CONV_DGRAD || mode == RUNET_CONVT_DGRAD);
     return names[kc ? 1 : 0][pick_variant((long)n_img * h * w_, cout)];
 }

@@ -136,35 +136,33 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel(WinoArgs g) {
     int uoff[2];              // columns n >= N read element 0 instead: their products land in output columns that are never stored
 #pragma unroll
     for (int b = 0; b < 2; ++b) uoff[b] = (n0 + b * 32 + li < g.N) ? lh * g.N + b * 32 + li : 0;
-    f32x4 bfa[2][2], bfb[2][2];
-    auto load_u = [&](int xl, int c0, f32x4 (&bf)[2][2]) {
+    // U fragments travel through a ring of four half-position slots (one slot = the two float4 of one (position, k-half)):
+    // the load for step t+3 is issued in front of step t's 8 MFMAs, i.e. every fragment has ~1500 MFMA cycles to arrive,
+    // with the same 32 registers a plain double buffer of whole positions would use.
+    f32x4 ring[4][2];
+    auto load_step = [&](int t, int c0, f32x4 (&slot)[2]) {
+        const int xl = t >> 1, kh = t & 1;
+        const f32x4* up = U4 + ((long)((wid * 4 + xl) * K4 + (c0 >> 2) + kh * 2) * g.N + n0);      // wave-uniform
 #pragma unroll
-        for (int kh = 0; kh < 2; ++kh) {
-            const f32x4* up = U4 + ((long)((wid * 4 + xl) * K4 + (c0 >> 2) + kh * 2) * g.N + n0);      // wave-uniform
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                if constexpr (ABL & 4) bf[kh][b] = f32x4{1.f, 2.f, 3.f, (float)c0};
-                else bf[kh][b] = up[uoff[b]];
-            }
+        for (int b = 0; b < 2; ++b) {
+            if constexpr (ABL & 4) slot[b] = f32x4{1.f, 2.f, 3.f, (float)c0};
+            else slot[b] = up[uoff[b]];
         }
     };
-    auto mma = [&](int xl, const f32x4 (&bf)[2][2]) {
-        const int xi = wid * 4 + xl;
-        const f32x4 a0 = *reinterpret_cast<const f32x4*>(&V[(xi * WT + li) * VLD + 4 * lh]);
-        const f32x4 a1 = *reinterpret_cast<const f32x4*>(&V[(xi * WT + li) * VLD + 8 + 4 * lh]);
+    auto mma_step = [&](int t, const f32x4 (&slot)[2]) {
+        const int xl = t >> 1, kh = t & 1;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(&V[((wid * 4 + xl) * WT + li) * VLD + kh * 8 + 4 * lh]);
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int b = 0; b < 2; ++b) acc[xl][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q], bf[0][b][q], acc[xl][b], 0, 0, 0);
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int b = 0; b < 2; ++b) acc[xl][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q], bf[1][b][q], acc[xl][b], 0, 0, 0);
+            for (int b = 0; b < 2; ++b) acc[xl][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], slot[b][q], acc[xl][b], 0, 0, 0);
     };
 
     const int nchunks = g.K >> 4;
     load_halo(0);
-    load_u(0, 0, bfa);
+    load_step(0, 0, ring[0]);
+    load_step(1, 0, ring[1]);
+    load_step(2, 0, ring[2]);
     for (int ch = 0; ch < nchunks; ++ch) {
         const int c0 = ch * 16;
         const int cn = (ch + 1 < nchunks) ? c0 + 16 : c0;      // last chunk: harmless re-read, keeps the code branch-free
@@ -172,25 +170,17 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel(WinoArgs g) {
         __syncthreads();                       // R complete; previous chunk's MFMA reads of V are done
         transform_store();
         __syncthreads();
-        // the sched_barriers pin each group of loads in FRONT of the 16 MFMAs it overlaps (the scheduler otherwise sinks the
-        // loads to the end of the region, two MFMAs ahead of their first use)
-        load_u(1, c0, bfb);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(0, bfa);                           // its U fragments were requested during the previous chunk
-        __builtin_amdgcn_sched_barrier(0);
-        load_halo(cn);                         // next chunk's halo: in flight during the rest of this chunk's MFMAs
-        load_u(2, c0, bfa);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(1, bfb);
-        __builtin_amdgcn_sched_barrier(0);
-        load_u(3, c0, bfb);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(2, bfa);
-        __builtin_amdgcn_sched_barrier(0);
-        load_u(0, cn, bfa);                    // position 0 of the NEXT chunk, in flight across the two barriers
-        __builtin_amdgcn_sched_barrier(0);
-        mma(3, bfb);
-        __builtin_amdgcn_sched_barrier(0);
+        // the sched_barriers pin each load group in FRONT of the MFMAs it overlaps (the scheduler otherwise sinks loads to the
+        // end of the region, right in front of their first use)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            if (t + 3 < 8) load_step(t + 3, c0, ring[(t + 3) & 3]);
+            else load_step(t + 3 - 8, cn, ring[(t + 3) & 3]);          // first steps of the NEXT chunk, in flight across the barriers
+            if (t == 1) load_halo(cn);                                 // next chunk's halo: in flight during the rest of the MFMAs
+            __builtin_amdgcn_sched_barrier(0);
+            mma_step(t, ring[t & 3]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 
     // ---- epilogue: exchange the 16 positions through LDS (16 output channels per pass), A^T m A, store ----
