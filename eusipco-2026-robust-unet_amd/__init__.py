@@ -16,7 +16,7 @@ import importlib as _il
 
 _LAZY = {
     "RobustUNet": "model", "ResidualBlock": "model", "DilatedBlock": "model", "AttentionGate": "model",
-    "ChannelAttention": "model", "SpatialAttention": "model",
+    "ChannelAttention": "model", "SpatialAttention": "model", "DeepLabV3Plus": "deeplab", "ASPP": "deeplab",
     "CoastalDataset": "data", "prepare_dataset": "data", "synthetic_batch": "data", "DevicePrefetcher": "data",
     "ModelEvaluator": "evaluator", "FusedAdam": "optim", "bce_loss": "ops", "GradAllReducer": "ddp",
     "TrainStep": "trainer", "fit": "trainer",

@@ -34,8 +34,11 @@ struct IGemmArgs {
     int Hin, Win, a_scale;        // source pixel = (h*a_scale + bh + r*tdh, w*a_scale + bw + s*tdw)
     int KH, KW, tdh, tdw, bh, bw;
     int Hout, Wout, o_scale, o_dh, o_dw;   // destination pixel = (h*o_scale + o_dh, w*o_scale + o_dw)
-    int z_taps;                   // >0: blockIdx.z selects one weight tap AND the destination offset (convT fwd)
+    int z_taps;                   // >0: blockIdx.z selects one weight tap AND the destination offset (convT k2 fwd)
     int accumulate;               // y += result
+    int a_div;                    // >1: source coordinate must be divisible by a_div and is divided by it (data gradient of a strided conv)
+    int zmode4;                   // 1: ConvTranspose2d(k4,s2,p1) forward: blockIdx.z = output parity class (ph,pw); taps (a,b) in 2x2 read
+                                  //    weight tap (1-ph+2a, 1-pw+2b) of the 4x4 filter at source offset (ph-a, pw-b)
 };
 
 template <int BM, int BN, int WM, int WN, bool KCONTIG>
@@ -64,6 +67,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IGemmArgs g) {
 
     const float* wbase = g.w;
     int o_dh = g.o_dh, o_dw = g.o_dw;
+    const int ph4 = blockIdx.z >> 1, pw4 = blockIdx.z & 1;
+    if (g.zmode4) { o_dh = ph4; o_dw = pw4; }
     if (g.z_taps > 0) {
         wbase += (long)blockIdx.z * g.w_tap_stride;
         o_dh = blockIdx.z / g.z_taps;   // z_taps = taps per row (2 for the 2x2 transposed conv)
@@ -97,17 +102,24 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IGemmArgs g) {
     int ld_tr = 0, ld_ts = 0, ld_kc = 0, ld_tap = 0;   // counters of the NEXT tile to load
 
     auto load_tile = [&]() {
-        const int dh = ld_tr * g.tdh, dw = ld_ts * g.tdw;
+        int dh = ld_tr * g.tdh, dw = ld_ts * g.tdw;
+        int wtap = ld_tap;
+        if (g.zmode4) { dh = ph4 - ld_tr; dw = pw4 - ld_ts; wtap = (1 - ph4 + 2 * ld_tr) * 4 + (1 - pw4 + 2 * ld_ts); }
         const int kofs = ld_kc * 16;
 #pragma unroll
         for (int i = 0; i < AROWS; ++i) {
-            const int ih = a_h[i] + dh, iw = a_w[i] + dw;
-            const bool ok = a_ok[i] && (unsigned)ih < (unsigned)g.Hin && (unsigned)iw < (unsigned)g.Win && kofs + akq * 4 < g.Kx;
+            int ih = a_h[i] + dh, iw = a_w[i] + dw;
+            bool ok = a_ok[i] && kofs + akq * 4 < g.Kx;
+            if (g.a_div > 1) {
+                ok = ok && ih >= 0 && iw >= 0 && (ih % g.a_div) == 0 && (iw % g.a_div) == 0;
+                ih /= g.a_div; iw /= g.a_div;
+            }
+            ok = ok && (unsigned)ih < (unsigned)g.Hin && (unsigned)iw < (unsigned)g.Win;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (ok) v = *reinterpret_cast<const f32x4*>(g.x + ((a_img[i] + (long)ih * g.Win + iw) * g.ldx + kofs + akq * 4));
             ra[i] = v;
         }
-        const float* wt = wbase + (long)ld_tap * g.w_tap_stride;
+        const float* wt = wbase + (long)wtap * g.w_tap_stride;
         if constexpr (!KCONTIG) {   // n contiguous: 16 k-rows x BN/4 float4
             constexpr int NQ = BN / 4;
             constexpr int KSTEP = 256 / NQ;
@@ -267,6 +279,7 @@ struct WGradArgs {
     int Hin, Win, a_scale, KH, KW, tdh, tdw, bh, bw;   // x pixel = (h*a_scale + bh + r*tdh, ...)
     int Hout, Wout, o_scale;     // dy pixel = (h*o_scale + o_dh, w*o_scale + o_dw)
     int tap_on_output;           // 1: tap (r,s) offsets the dy pixel (transposed conv), x pixel unshifted
+    int o_bh, o_bw;              // base offset of the dy pixel when tap_on_output (k4-s2-p1 transposed conv: -1)
     long pix_per_split;          // multiple of 16
 };
 
@@ -295,7 +308,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WGradArgs g) {
     const int HW = g.H * g.W;
 
     int xdh = g.bh, xdw = g.bw, ydh = 0, ydw = 0;
-    if (g.tap_on_output) { ydh = tr; ydw = ts; } else { xdh += tr * g.tdh; xdw += ts * g.tdw; }
+    if (g.tap_on_output) { ydh = tr + g.o_bh; ydw = ts + g.o_bw; } else { xdh += tr * g.tdh; xdw += ts * g.tdw; }
 
     f32x4 ra[AREGS], rb[BREGS];
     auto load_tile = [&](long pk) {   // pk: first pixel of the 16-pixel k-step
@@ -323,8 +336,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WGradArgs g) {
                 const int n = (int)(p / HW);
                 const int rem = (int)(p - (long)n * HW);
                 const int h = rem / g.W, w = rem - h * g.W;
-                const long op = ((long)n * g.Hout + (h * g.o_scale + ydh)) * g.Wout + (w * g.o_scale + ydw);
-                v = *reinterpret_cast<const f32x4*>(g.dy + op * g.ldy + co0 + cq * 4);
+                const int oh = h * g.o_scale + ydh, ow = w * g.o_scale + ydw;
+                if ((unsigned)oh < (unsigned)g.Hout && (unsigned)ow < (unsigned)g.Wout)
+                    v = *reinterpret_cast<const f32x4*>(g.dy + (((long)n * g.Hout + oh) * g.Wout + ow) * g.ldy + co0 + cq * 4);
             }
             rb[i] = v;
         }
@@ -887,5 +901,114 @@ extern "C" int runet_conv_wgrad(const float* x, int ldx, const float* dy, int ld
         const int thr = 256;
         hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(wsize, 32 * 4)), dim3(256), 0, st, workspace, dw, wsize, splits);
     }
+    RUNET_CHECK_LAUNCH();
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// General (strided / large-kernel / k4 transposed) convolutions for the DeepLabV3+ baseline (/root/reference/Main_Final.py:325-433:
+// Conv2d 7x7 s2 p3, 3x3 s2 p1, 3x3 dilation 6/12/18, ConvTranspose2d k4 s2 p1).  Same kernels, other geometry.
+extern "C" int runet_conv2d_general(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int n_img, int hin,
+                                    int win, int cin, int cin_w, int cout, int kh, int kw, int stride, int pad, int dil, int mode,
+                                    int accumulate, void* stream) {
+    RUNET_REQUIRE(x && w && y, "null pointer");
+    RUNET_REQUIRE(cin > 0 && cin % 4 == 0 && cin_w > 0 && cin_w <= cin && cout > 0 && cout % 4 == 0, "channel counts must be multiples of 4");
+    RUNET_REQUIRE(kh >= 1 && kh <= 7 && kw >= 1 && kw <= 7 && stride >= 1 && stride <= 2 && pad >= 0 && dil >= 1, "unsupported geometry");
+    RUNET_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0 && ((uintptr_t)y % 16) == 0, "alignment");
+    const int ho = (hin + 2 * pad - dil * (kh - 1) - 1) / stride + 1, wo = (win + 2 * pad - dil * (kw - 1) - 1) / stride + 1;
+    RUNET_REQUIRE(ho > 0 && wo > 0, "empty output");
+    hipStream_t st = (hipStream_t)stream;
+    IGemmArgs a{};
+    a.x = x; a.ldx = ldx; a.w = w; a.bias = bias; a.y = y; a.ldy = ldy; a.Nimg = n_img; a.accumulate = accumulate; a.KH = kh; a.KW = kw;
+    a.a_div = 1; a.o_scale = 1;
+    if (mode == RUNET_CONV_FWD) {          // x [n,hin,win,cin] -> y [n,ho,wo,cout]
+        RUNET_REQUIRE(ldx >= cin && ldy >= cout, "bad pixel strides");
+        a.K = (cin + 15) / 16 * 16; a.Kx = cin; a.Kvalid = cin_w; a.Ncols = cout;
+        a.w_tap_stride = (long)cin_w * cout; a.w_sk = cout; a.w_sn = 1;
+        a.H = ho; a.W = wo; a.Hin = hin; a.Win = win; a.a_scale = stride; a.tdh = dil; a.tdw = dil; a.bh = -pad; a.bw = -pad;
+        a.Hout = ho; a.Wout = wo;
+        dispatch_igemm<false>(a, 1, st);
+    } else if (mode == RUNET_CONV_DGRAD) { // x := dy [n,ho,wo,cin(=conv Cout)] -> y := dx [n,hin,win,cout(=conv Cin)]; w [kh,kw,cout,cin]
+        RUNET_REQUIRE(cin_w == cin && ldx >= cin && ldy >= cout, "bad arguments for the data gradient");
+        a.K = (cin + 15) / 16 * 16; a.Kx = cin; a.Kvalid = cin; a.Ncols = cout;
+        a.w_tap_stride = (long)cout * cin; a.w_sk = 1; a.w_sn = cin;
+        a.H = hin; a.W = win; a.Hin = ho; a.Win = wo; a.a_scale = 1; a.tdh = -dil; a.tdw = -dil; a.bh = pad; a.bw = pad; a.a_div = stride;
+        a.Hout = hin; a.Wout = win;
+        dispatch_igemm<true>(a, 1, st);
+    } else {
+        RUNET_REQUIRE(false, "mode must be RUNET_CONV_FWD or RUNET_CONV_DGRAD");
+    }
+    RUNET_CHECK_LAUNCH();
+}
+
+// ConvTranspose2d(k4, s2, p1): w [4][4][cin][cout].  FWD: x [n,h,w,cin] -> y [n,2h,2w,cout];  DGRAD: x := dy [n,2h,2w,cin(=Cout)] -> y := dx [n,h,w,cout(=Cin)]
+extern "C" int runet_convt4_igemm(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int n_img, int h, int w_,
+                                  int cin, int cout, int mode, int accumulate, void* stream) {
+    RUNET_REQUIRE(x && w && y && cin % 4 == 0 && cout % 4 == 0 && cin > 0 && cout > 0, "bad arguments");
+    RUNET_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0 && ((uintptr_t)y % 16) == 0, "alignment");
+    hipStream_t st = (hipStream_t)stream;
+    IGemmArgs a{};
+    a.x = x; a.ldx = ldx; a.w = w; a.bias = bias; a.y = y; a.ldy = ldy; a.Nimg = n_img; a.accumulate = accumulate; a.a_div = 1;
+    a.K = (cin + 15) / 16 * 16; a.Kx = cin; a.Kvalid = cin; a.Ncols = cout; a.H = h; a.W = w_;
+    if (mode == RUNET_CONVT_FWD) {
+        a.w_tap_stride = (long)cin * cout; a.w_sk = cout; a.w_sn = 1;
+        a.Hin = h; a.Win = w_; a.a_scale = 1; a.KH = 2; a.KW = 2; a.zmode4 = 1;
+        a.Hout = 2 * h; a.Wout = 2 * w_; a.o_scale = 2;
+        dispatch_igemm<false>(a, 4, st);
+    } else if (mode == RUNET_CONVT_DGRAD) {
+        a.w_tap_stride = (long)cout * cin; a.w_sk = 1; a.w_sn = cin;
+        a.Hin = 2 * h; a.Win = 2 * w_; a.a_scale = 2; a.KH = 4; a.KW = 4; a.tdh = 1; a.tdw = 1; a.bh = -1; a.bw = -1;
+        a.Hout = h; a.Wout = w_; a.o_scale = 1;
+        dispatch_igemm<true>(a, 1, st);
+    } else {
+        RUNET_REQUIRE(false, "mode must be RUNET_CONVT_FWD or RUNET_CONVT_DGRAD");
+    }
+    RUNET_CHECK_LAUNCH();
+}
+
+// weight gradient for the general geometries (per-tap split-K kernel).  transposed4 != 0: ConvTranspose2d(k4,s2,p1), x [n,h,w,cin], dy [n,2h,2w,cout].
+extern "C" long runet_conv_wgrad_general_workspace_floats(int pixels, int cin_w, int cout, int kh, int kw) {
+    bool big; int tiles, splits;
+    wgrad_plan(pixels, cin_w, cout, kh * kw, big, tiles, splits);
+    return splits > 1 ? (long)splits * kh * kw * cin_w * cout : 0;
+}
+
+extern "C" int runet_conv_wgrad_general(const float* x, int ldx, const float* dy, int ldy, float* dw, float* workspace, long workspace_floats,
+                                        int n_img, int hin, int win, int cin, int cin_w, int cout, int kh, int kw, int stride, int pad, int dil,
+                                        int transposed4, void* stream) {
+    RUNET_REQUIRE(x && dy && dw, "null pointer");
+    RUNET_REQUIRE(cin % 4 == 0 && cin_w > 0 && cin_w <= cin && cout % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, "channel counts / strides must be multiples of 4");
+    hipStream_t st = (hipStream_t)stream;
+    WGradArgs a{};
+    a.x = x; a.ldx = ldx; a.dy = dy; a.ldy = ldy; a.Kci = cin; a.Kvalid = cin_w; a.Nco = cout; a.Nimg = n_img; a.KH = kh; a.KW = kw;
+    long P;
+    if (transposed4) {
+        RUNET_REQUIRE(kh == 4 && kw == 4, "transposed4 is the k4-s2-p1 transposed convolution");
+        a.H = hin; a.W = win; a.Hin = hin; a.Win = win; a.a_scale = 1; a.tap_on_output = 1; a.o_bh = -1; a.o_bw = -1;
+        a.Hout = 2 * hin; a.Wout = 2 * win; a.o_scale = 2;
+        P = (long)n_img * hin * win;
+    } else {
+        const int ho = (hin + 2 * pad - dil * (kh - 1) - 1) / stride + 1, wo = (win + 2 * pad - dil * (kw - 1) - 1) / stride + 1;
+        a.H = ho; a.W = wo; a.Hin = hin; a.Win = win; a.a_scale = stride; a.tdh = dil; a.tdw = dil; a.bh = -pad; a.bw = -pad;
+        a.Hout = ho; a.Wout = wo; a.o_scale = 1;
+        P = (long)n_img * ho * wo;
+    }
+    const int ntaps = kh * kw;
+    bool big; int tiles, splits;
+    wgrad_plan(P, cin_w, cout, ntaps, big, tiles, splits);
+    const long wsize = (long)ntaps * cin_w * cout;
+    if (splits > 1 && (workspace == nullptr || workspace_floats < splits * wsize)) {
+        splits = workspace ? (int)(workspace_floats / wsize) : 1;
+        if (splits < 1) splits = 1;
+    }
+    long pps = (P + splits - 1) / splits;
+    pps = (pps + 15) / 16 * 16;
+    splits = cdiv(P, pps);
+    a.pix_per_split = pps;
+    a.out = (splits > 1) ? workspace : dw;
+    dim3 grid(tiles, ntaps, splits);
+    if (big) hipLaunchKernelGGL((wgrad_kernel<128, 128, 64, 64>), grid, dim3(256), 2 * (16 * (128 + 4) * 2) * sizeof(float), st, a);
+    else hipLaunchKernelGGL((wgrad_kernel<64, 64, 32, 32>), grid, dim3(256), 2 * (16 * (64 + 4) * 2) * sizeof(float), st, a);
+    if (splits > 1) hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(wsize, 32 * 4)), dim3(256), 0, st, workspace, dw, wsize, splits);
     RUNET_CHECK_LAUNCH();
 }

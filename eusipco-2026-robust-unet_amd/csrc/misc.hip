@@ -239,3 +239,206 @@ extern "C" int runet_seg_counts(const float* pred, const float* target, long lon
     hipLaunchKernelGGL(seg_counts_kernel, dim3((int)b, n_img), dim3(TPB), 0, st, pred, target, counts, per_img, threshold);
     RUNET_CHECK_LAUNCH();
 }
+
+// ============================================================================================================================
+// DeepLabV3+ baseline extras (/root/reference/Main_Final.py:325-433): MaxPool2d(3, stride 2, padding 1), the ASPP image-pooling
+// branch (global average -> 1x1 conv -> bilinear upsample of a 1x1 map = broadcast) and the final Conv2d(16, 1, 3, padding 1) + sigmoid.
+namespace {
+// ---- MaxPool2d(3, s2, p1): idx byte = window position (0..8) of the first maximum in scan order
+__global__ __launch_bounds__(TPB) void maxpool3s2_fwd_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy,
+                                                             unsigned char* __restrict__ idx, int N, int H, int W, int Ho, int Wo, int C) {
+    const int cvec = C / 4;
+    const long total = (long)N * Ho * Wo * cvec;
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
+        const long op = i / cvec;
+        const int c = (int)(i - op * cvec) * 4;
+        const int wo = (int)(op % Wo);
+        const long t = op / Wo;
+        const int ho = (int)(t % Ho);
+        const long n = t / Ho;
+        f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        unsigned int sel[4] = {0, 0, 0, 0};
+        bool first = true;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int ih = 2 * ho - 1 + k / 3, iw = 2 * wo - 1 + k % 3;
+            if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(x + ((n * H + ih) * W + iw) * ldx + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (first || v[e] > m[e] || v[e] != v[e]) { m[e] = v[e]; sel[e] = k; }
+                first = false;
+            }
+        }
+        *reinterpret_cast<f32x4*>(y + op * ldy + c) = m;
+        *reinterpret_cast<unsigned int*>(idx + op * C + c) = sel[0] | (sel[1] << 8) | (sel[2] << 16) | (sel[3] << 24);
+    }
+}
+// gather form: input pixel (ih, iw) belongs to the windows ho in {(ih+1)/2 - (0|1)} ...
+__global__ __launch_bounds__(TPB) void maxpool3s2_bwd_kernel(const float* __restrict__ dy, int lddy, const unsigned char* __restrict__ idx,
+                                                             float* __restrict__ dx, int lddx, int N, int H, int W, int Ho, int Wo, int C) {
+    const int cvec = C / 4;
+    const long total = (long)N * H * W * cvec;
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
+        const long ip = i / cvec;
+        const int c = (int)(i - ip * cvec) * 4;
+        const int iw = (int)(ip % W);
+        const long t = ip / W;
+        const int ih = (int)(t % H);
+        const long n = t / H;
+        f32x4 g = {0.f, 0.f, 0.f, 0.f};
+        for (int ho = (ih + 1) / 2 - 1 + ((ih + 1) & 1 ? 0 : 0); ho <= (ih + 1) / 2; ++ho) {
+            if (ho < 0 || ho >= Ho) continue;
+            const int kr = ih - (2 * ho - 1);
+            if (kr < 0 || kr > 2) continue;
+            for (int wo = (iw + 1) / 2 - 1; wo <= (iw + 1) / 2; ++wo) {
+                if (wo < 0 || wo >= Wo) continue;
+                const int kc = iw - (2 * wo - 1);
+                if (kc < 0 || kc > 2) continue;
+                const long op = (n * Ho + ho) * Wo + wo;
+                const unsigned int s = *reinterpret_cast<const unsigned int*>(idx + op * C + c);
+                const f32x4 d = *reinterpret_cast<const f32x4*>(dy + op * lddy + c);
+                const unsigned k = kr * 3 + kc;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (((s >> (8 * e)) & 0xff) == k) g[e] += d[e];
+            }
+        }
+        *reinterpret_cast<f32x4*>(dx + ip * lddx + c) = g;
+    }
+}
+// y[n, p, c] = v[n, c]
+__global__ __launch_bounds__(TPB) void broadcast_nc_kernel(const float* __restrict__ v, float* __restrict__ y, int ldy, int HW, int C, long total) {
+    const int cvec = C / 4;
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
+        const long p = i / cvec;
+        const int c = (int)(i - p * cvec) * 4;
+        const long n = p / HW;
+        *reinterpret_cast<f32x4*>(y + p * ldy + c) = *reinterpret_cast<const f32x4*>(v + n * C + c);
+    }
+}
+// final head: logit[p] = b + sum_{tap,c} x[p+tap][c] * w[tap][c];  prob = sigmoid
+__global__ __launch_bounds__(TPB) void head3x3_fwd_kernel(const float* __restrict__ x, int ld, const float* __restrict__ w,
+                                                          const float* __restrict__ b, float* __restrict__ prob, int N, int H, int W, int C) {
+    extern __shared__ float ws[];
+    for (int i = threadIdx.x; i < 9 * C; i += TPB) ws[i] = w[i];
+    __syncthreads();
+    const long total = (long)N * H * W;
+    for (long p = (long)blockIdx.x * TPB + threadIdx.x; p < total; p += (long)gridDim.x * TPB) {
+        const int wq = (int)(p % W);
+        const long t = p / W;
+        const int h = (int)(t % H);
+        const long n = t / H;
+        float acc = b[0];
+        for (int k = 0; k < 9; ++k) {
+            const int ih = h - 1 + k / 3, iw = wq - 1 + k % 3;
+            if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
+                const float* xp = x + ((n * H + ih) * W + iw) * ld;
+                for (int c = 0; c < C; c += 4) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(xp + c);
+                    acc += v[0] * ws[k * C + c] + v[1] * ws[k * C + c + 1] + v[2] * ws[k * C + c + 2] + v[3] * ws[k * C + c + 3];
+                }
+            }
+        }
+        prob[p] = sigmoidf_(acc);
+    }
+}
+// dl = dprob*p*(1-p);  dx[p][c] = sum_tap dl[p - tap] * w[tap][c];  partial dw[tap][c] = sum_p x[p+tap][c]*dl[p], db = sum dl
+__global__ __launch_bounds__(TPB) void head3x3_bwd_kernel(const float* __restrict__ dprob, const float* __restrict__ prob,
+                                                          const float* __restrict__ x, int ld, const float* __restrict__ w,
+                                                          float* __restrict__ dx, int lddx, float* __restrict__ part, int N, int H, int W, int C) {
+    extern __shared__ float sm[];
+    float* ws = sm;                    // [9*C]
+    float* red = sm + 9 * C;           // [9*C + 1] block partial
+    for (int i = threadIdx.x; i < 9 * C; i += TPB) ws[i] = w[i];
+    for (int i = threadIdx.x; i < 9 * C + 1; i += TPB) red[i] = 0.f;
+    __syncthreads();
+    const long total = (long)N * H * W;
+    for (long p = (long)blockIdx.x * TPB + threadIdx.x; p < total; p += (long)gridDim.x * TPB) {
+        const int wq = (int)(p % W);
+        const long t = p / W;
+        const int h = (int)(t % H);
+        const long n = t / H;
+        const float pr = prob[p];
+        const float dl = dprob[p] * pr * (1.f - pr);
+        atomicAdd(&red[9 * C], dl);
+        for (int c = 0; c < C; ++c) {
+            float g = 0.f;
+            for (int k = 0; k < 9; ++k) {
+                const int oh = h + 1 - k / 3, ow = wq + 1 - k % 3;      // output pixel whose tap k reads this input pixel
+                if ((unsigned)oh < (unsigned)H && (unsigned)ow < (unsigned)W) {
+                    const long q = (n * H + oh) * W + ow;
+                    const float pq = prob[q];
+                    g += dprob[q] * pq * (1.f - pq) * ws[k * C + c];
+                }
+            }
+            dx[p * lddx + c] = g;
+        }
+        for (int k = 0; k < 9; ++k) {
+            const int ih = h - 1 + k / 3, iw = wq - 1 + k % 3;
+            if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
+                const float* xp = x + ((n * H + ih) * W + iw) * ld;
+                for (int c = 0; c < C; ++c) atomicAdd(&red[k * C + c], xp[c] * dl);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 9 * C + 1; i += TPB) part[(long)blockIdx.x * (9 * C + 1) + i] = red[i];
+}
+__global__ void sum_rows_kernel(const float* __restrict__ part, int nrows, int ncols, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncols) return;
+    double a = 0;
+    for (int r = 0; r < nrows; ++r) a += part[(long)r * ncols + c];
+    out[c] = (float)a;
+}
+}  // namespace
+
+extern "C" int runet_maxpool3s2_fwd(const float* x, int ldx, float* y, int ldy, unsigned char* idx, int n_img, int h, int w, int c, void* stream) {
+    RUNET_REQUIRE(x && y && idx && c % 4 == 0 && c > 0 && h > 0 && w > 0, "bad arguments");
+    const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
+    hipLaunchKernelGGL(maxpool3s2_fwd_kernel, dim3(ew_grid((long)n_img * ho * wo * (c / 4))), dim3(TPB), 0, (hipStream_t)stream, x, ldx, y, ldy, idx, n_img, h, w, ho, wo, c);
+    RUNET_CHECK_LAUNCH();
+}
+extern "C" int runet_maxpool3s2_bwd(const float* dy, int lddy, const unsigned char* idx, float* dx, int lddx, int n_img, int h, int w, int c, void* stream) {
+    RUNET_REQUIRE(dy && dx && idx && c % 4 == 0 && c > 0, "bad arguments");
+    const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
+    hipLaunchKernelGGL(maxpool3s2_bwd_kernel, dim3(ew_grid((long)n_img * h * w * (c / 4))), dim3(TPB), 0, (hipStream_t)stream, dy, lddy, idx, dx, lddx, n_img, h, w, ho, wo, c);
+    RUNET_CHECK_LAUNCH();
+}
+extern "C" int runet_broadcast_nc(const float* v_nc, float* y, int ldy, int n_img, int hw, int c, void* stream) {
+    RUNET_REQUIRE(v_nc && y && c % 4 == 0 && c > 0, "bad arguments");
+    const long total = (long)n_img * hw * (c / 4);
+    hipLaunchKernelGGL(broadcast_nc_kernel, dim3(ew_grid(total)), dim3(TPB), 0, (hipStream_t)stream, v_nc, y, ldy, hw, c, total);
+    RUNET_CHECK_LAUNCH();
+}
+extern "C" int runet_head3x3_fwd(const float* x, int ld, const float* w, const float* b, float* prob, int n_img, int h, int w_, int c, void* stream) {
+    RUNET_REQUIRE(x && w && b && prob && c % 4 == 0 && c > 0 && c <= 64, "bad arguments (c multiple of 4, <= 64)");
+    hipLaunchKernelGGL(head3x3_fwd_kernel, dim3(ew_grid((long)n_img * h * w_)), dim3(TPB), 9 * c * sizeof(float), (hipStream_t)stream, x, ld, w, b, prob, n_img, h, w_, c);
+    RUNET_CHECK_LAUNCH();
+}
+extern "C" long runet_head3x3_bwd_workspace_floats(int n_img, int h, int w_, int c) { return 1024L * (9 * c + 1); }
+extern "C" int runet_head3x3_bwd(const float* dprob, const float* prob, const float* x, int ld, const float* w, float* dx, int lddx, float* workspace,
+                                 float* dw_db, int n_img, int h, int w_, int c, void* stream) {
+    RUNET_REQUIRE(dprob && prob && x && w && dx && workspace && dw_db && c % 4 == 0 && c > 0 && c <= 64, "bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    long blocks = ((long)n_img * h * w_ + TPB - 1) / TPB;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(head3x3_bwd_kernel, dim3((int)blocks), dim3(TPB), (18 * c + 1) * sizeof(float), st, dprob, prob, x, ld, w, dx, lddx, workspace, n_img, h, w_, c);
+    hipLaunchKernelGGL(sum_rows_kernel, dim3(cdiv(9 * c + 1, 128)), dim3(128), 0, st, workspace, (int)blocks, 9 * c + 1, dw_db);
+    RUNET_CHECK_LAUNCH();
+}
+
+namespace {
+__global__ __launch_bounds__(TPB) void add_inplace_kernel(float* __restrict__ dst, const float* __restrict__ src, long n) {
+    const long nv = n / 4;
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < nv; i += (long)gridDim.x * TPB)
+        reinterpret_cast<f32x4*>(dst)[i] += reinterpret_cast<const f32x4*>(src)[i];
+    for (long i = nv * 4 + (long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long)gridDim.x * TPB) dst[i] += src[i];
+}
+}  // namespace
+extern "C" int runet_add_inplace(float* dst, const float* src, long n, void* stream) {
+    RUNET_REQUIRE(dst && src && n > 0 && ((uintptr_t)dst % 16) == 0 && ((uintptr_t)src % 16) == 0, "bad arguments");
+    hipLaunchKernelGGL(add_inplace_kernel, dim3(ew_grid(n / 4 + 1)), dim3(TPB), 0, (hipStream_t)stream, dst, src, n);
+    RUNET_CHECK_LAUNCH();
+}

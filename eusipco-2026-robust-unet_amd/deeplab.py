@@ -1,0 +1,280 @@
+"""`DeepLabV3Plus` baseline of the reference (/root/reference/Main_Final.py:325-433, duplicated in
+Extended_Baseline_Comparison.py:293-337) on the same gfx950 kernels as the Robust U-Net path (BASELINE.json config 4:
+"shared implicit-GEMM conv kernels").  Same constructor, attribute tree and state_dict keys as the reference; the
+forward returns sigmoid probabilities like the reference's `torch.sigmoid(x)`.
+
+Geometry beyond the U-Net's: Conv2d 7x7 stride 2, 3x3 stride 2, 3x3 dilation 6/12/18, MaxPool2d(3, s2, p1),
+global-average-pool -> 1x1 conv -> bilinear upsample of a 1x1 map (= broadcast), ConvTranspose2d(k4, s2, p1) and a
+Conv2d(16, 1, 3) head.  Forward and backward are explicit kernel sequences (one autograd node), NHWC fp32.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+
+from . import blocks as B
+from . import ops
+from ._lib import check, lib
+from .model import BatchNorm2d, Conv2d, _Act, _Holder, _require_cuda
+
+
+class ConvTranspose2dK4(_Holder):
+    """ConvTranspose2d(cin, cout, 4, stride=2, padding=1) parameter holder; weight logical [cin, cout, 4, 4], memory [4][4][cin][cout]."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=4, stride=2, padding=1):
+        super().__init__()
+        assert (kernel_size, stride, padding) == (4, 2, 1)
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.weight = nn.Parameter(torch.empty(4, 4, in_channels, out_channels).permute(2, 3, 0, 1))
+        self.bias = nn.Parameter(torch.empty(out_channels))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        bound = 1.0 / math.sqrt(out_channels * 16)
+        nn.init.uniform_(self.bias, -bound, bound)
+
+
+class _MaxPool3(_Holder):
+    pass
+
+
+class ASPP(nn.Module):
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.conv1 = Conv2d(in_channels, out_channels, 1)
+        self.conv2 = Conv2d(in_channels, out_channels, 3, padding=6, dilation=6)
+        self.conv3 = Conv2d(in_channels, out_channels, 3, padding=12, dilation=12)
+        self.conv4 = Conv2d(in_channels, out_channels, 3, padding=18, dilation=18)
+        self.global_pool = _Act()
+        self.conv5 = Conv2d(in_channels, out_channels, 1)
+        self.conv_out = Conv2d(out_channels * 5, out_channels, 1)
+        self.bn = BatchNorm2d(out_channels)
+
+    def forward(self, x):
+        raise NotImplementedError("ASPP is executed inside DeepLabV3Plus.forward's kernel sequence")
+
+
+class DeepLabV3Plus(nn.Module):
+    """forward(x: float32 [N, 3, H, W], H and W multiples of 16) -> sigmoid probabilities [N, 1, H, W]."""
+
+    DEC = ((256, 128), (128, 64), (64, 32), (32, 16))
+
+    def __init__(self, n_classes=1):
+        super().__init__()
+        if n_classes != 1:
+            raise ValueError("the fused head implements the reference's n_classes=1 sigmoid head")
+        self.conv1 = nn.Sequential(Conv2d(3, 64, 7, padding=3, stride=2), BatchNorm2d(64), _Act())
+        self.conv2 = nn.Sequential(_MaxPool3(), Conv2d(64, 128, 3, padding=1), BatchNorm2d(128), _Act())
+        self.conv3 = nn.Sequential(Conv2d(128, 256, 3, padding=1, stride=2), BatchNorm2d(256), _Act())
+        self.conv4 = nn.Sequential(Conv2d(256, 512, 3, padding=1, stride=2), BatchNorm2d(512), _Act())
+        self.aspp = ASPP(512, 256)
+        dec = []
+        for cin, cout in self.DEC:
+            dec += [ConvTranspose2dK4(cin, cout), BatchNorm2d(cout), _Act()]
+        dec.append(Conv2d(16, n_classes, 3, padding=1))
+        self.decoder = nn.Sequential(*dec)
+
+    def forward(self, x):
+        _require_cuda(x)
+        if x.shape[2] % 16 or x.shape[3] % 16:
+            raise ValueError("H and W must be multiples of 16")
+        names = [k for k, _ in self.named_parameters()]
+        params = [p for _, p in self.named_parameters()]
+        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            return _DeepLabFn.apply(x, self, names, *params)
+        return dl_forward(self, x, save=False)[0]
+
+
+def _conv_bn_relu(x, conv, bn, training, sm, fwd):
+    """fwd(x, w_hwio, bias) -> raw conv output; then train/eval BN + ReLU.  -> (act, ctx)"""
+    w = ops.hwio(conv.weight)
+    raw = fwd(x, w, conv.bias)
+    s, h, mean, invstd, _ = B.bn_coeff(raw, bn.state(), training, sm)
+    act = B.bn_apply(raw, s, h, None, relu=True)
+    return act, dict(x=x, w=w, raw=raw, act=act, s=s, mean=mean, invstd=invstd)
+
+
+def dl_forward(net: DeepLabV3Plus, x, save=True):
+    tr = net.training
+    dev = x.device
+    sm = B.Small(dev)
+    n = x.shape[0]
+    C = {}
+    x0 = B.to_nhwc_pad(x, 4)
+    a1, C["conv1"] = _conv_bn_relu(x0, net.conv1[0], net.conv1[1], tr, sm, lambda t, w, b: ops.conv_general_fwd(t, w, b, 2, 3))
+    _, h1, w1, c1 = a1.shape
+    ho, wo = (h1 + 2 - 3) // 2 + 1, (w1 + 2 - 3) // 2 + 1
+    p1 = ops.empty_nhwc(n, ho, wo, c1, a1)
+    idx = torch.empty((n, ho, wo, c1), device=dev, dtype=torch.uint8)
+    check(lib.runet_maxpool3s2_fwd(a1.data_ptr(), ops.ld(a1), p1.data_ptr(), ops.ld(p1), idx.data_ptr(), n, h1, w1, c1, ops.stream()))
+    C["pool"] = (idx, h1, w1)
+    a2, C["conv2"] = _conv_bn_relu(p1, net.conv2[1], net.conv2[2], tr, sm, lambda t, w, b: ops.conv_fwd(t, w, b))
+    a3, C["conv3"] = _conv_bn_relu(a2, net.conv3[0], net.conv3[1], tr, sm, lambda t, w, b: ops.conv_general_fwd(t, w, b, 2, 1))
+    a4, C["conv4"] = _conv_bn_relu(a3, net.conv4[0], net.conv4[1], tr, sm, lambda t, w, b: ops.conv_general_fwd(t, w, b, 2, 1))
+    # ---- ASPP
+    asp = net.aspp
+    _, h4, w4, c4 = a4.shape
+    q = asp.conv1.out_channels
+    cat = ops.empty_nhwc(n, h4, w4, 5 * q, a4)
+    ws = [ops.hwio(c.weight) for c in (asp.conv1, asp.conv2, asp.conv3, asp.conv4, asp.conv5, asp.conv_out)]
+    ops.conv_fwd(a4, ws[0], asp.conv1.bias, out=cat[..., 0:q])
+    for i, (cv, d) in enumerate(((asp.conv2, 6), (asp.conv3, 12), (asp.conv4, 18))):
+        ops.conv_general_fwd(a4, ws[1 + i], cv.bias, 1, d, d, out=cat[..., (1 + i) * q:(2 + i) * q])
+    pooled, m2 = sm.f(n * c4), sm.f(n * c4)
+    wsp = B._ws(n, h4 * w4, c4, dev)
+    check(lib.runet_chan_stats(a4.data_ptr(), ops.ld(a4), n, h4 * w4, c4, wsp.data_ptr(), pooled.data_ptr(), m2.data_ptr(), None, None, None, None, 0,
+                               ops.stream()))
+    pooled4 = pooled.view(n, 1, 1, c4)
+    x5 = ops.conv_fwd(pooled4, ws[4], asp.conv5.bias)                       # [n,1,1,q]
+    check(lib.runet_broadcast_nc(x5.data_ptr(), cat[..., 4 * q:].data_ptr(), ops.ld(cat), n, h4 * w4, q, ops.stream()))
+    co = ops.conv_fwd(cat, ws[5], asp.conv_out.bias)
+    s, hsh, mean, invstd, _ = B.bn_coeff(co, asp.bn.state(), tr, sm)
+    aa = B.bn_apply(co, s, hsh, None, relu=True)
+    C["aspp"] = dict(a4=a4, cat=cat, pooled4=pooled4, ws=ws, co=co, aa=aa, s=s, mean=mean, invstd=invstd, q=q)
+    # ---- decoder
+    y = aa
+    for i in range(4):
+        ct, bn = net.decoder[3 * i], net.decoder[3 * i + 1]
+        w = ops.hwio_t(ct.weight)
+        raw = ops.convt4_fwd(y, w, ct.bias)
+        s, hsh, mean, invstd, _ = B.bn_coeff(raw, bn.state(), tr, sm)
+        act = B.bn_apply(raw, s, hsh, None, relu=True)
+        C[f"dec{i}"] = dict(x=y, w=w, raw=raw, act=act, s=s, mean=mean, invstd=invstd)
+        y = act
+    head = net.decoder[12]
+    wh = ops.hwio(head.weight)
+    nn_, hh, wh_, ch = y.shape
+    prob = torch.empty((nn_, 1, hh, wh_), device=dev, dtype=torch.float32)
+    check(lib.runet_head3x3_fwd(y.data_ptr(), ops.ld(y), wh.data_ptr(), head.bias.data_ptr(), prob.data_ptr(), nn_, hh, wh_, ch, ops.stream()))
+    C["head"] = (y, wh, prob)
+    return prob, (C if save else None)
+
+
+def dl_backward(net: DeepLabV3Plus, C, dprob):
+    """-> {parameter name: gradient with the parameter's logical shape}"""
+    G = {}
+    dev = dprob.device
+    sm = B.Small(dev)
+    st = ops.stream()
+
+    def conv_w(name, t):
+        G[name] = t.permute(3, 2, 0, 1)
+
+    def bn_back(prefix, c, dy):
+        nc = c["raw"].shape[3]
+        sums = torch.empty(2 * nc, device=dev, dtype=torch.float32)
+        dx = B.bn_backward(dy, c["raw"], c["mean"], c["invstd"], c["s"], sums, act=c["act"])
+        G[prefix + ".weight"], G[prefix + ".bias"] = sums[:nc], sums[nc:]
+        return dx
+
+    def bias_grad(name, t):
+        out = torch.empty(t.shape[3], device=dev, dtype=torch.float32)
+        B.chan_sum(t, out)
+        G[name] = out
+
+    y, wh, prob = C["head"]
+    n, hh, ww, ch = y.shape
+    dy = ops.empty_nhwc(n, hh, ww, ch, y)
+    dwdb = torch.empty(9 * ch + 1, device=dev, dtype=torch.float32)
+    wsb = B.scratch(lib.runet_head3x3_bwd_workspace_floats(n, hh, ww, ch), dev)
+    check(lib.runet_head3x3_bwd(dprob.data_ptr(), prob.data_ptr(), y.data_ptr(), ops.ld(y), wh.data_ptr(), dy.data_ptr(), ops.ld(dy), wsb.data_ptr(),
+                                dwdb.data_ptr(), n, hh, ww, ch, st))
+    G["decoder.12.weight"] = dwdb[:9 * ch].view(3, 3, ch, 1).permute(3, 2, 0, 1)
+    G["decoder.12.bias"] = dwdb[9 * ch:]
+    for i in (3, 2, 1, 0):
+        c = C[f"dec{i}"]
+        draw = bn_back(f"decoder.{3 * i + 1}", c, dy)
+        G[f"decoder.{3 * i}.weight"] = ops.convt4_wgrad(c["x"], draw).permute(2, 3, 0, 1)
+        bias_grad(f"decoder.{3 * i}.bias", draw)
+        dy = ops.convt4_dgrad(draw, c["w"])
+    # ---- ASPP
+    a = C["aspp"]
+    asp = net.aspp
+    q = a["q"]
+    nco = a["co"].shape[3]
+    sums = torch.empty(2 * nco, device=dev, dtype=torch.float32)
+    dco = B.bn_backward(dy, a["co"], a["mean"], a["invstd"], a["s"], sums, act=a["aa"])
+    G["aspp.bn.weight"], G["aspp.bn.bias"] = sums[:nco], sums[nco:]
+    ws = a["ws"]
+    cat, a4 = a["cat"], a["a4"]
+    conv_w("aspp.conv_out.weight", ops.conv_wgrad(cat, dco, 1, 1))
+    bias_grad("aspp.conv_out.bias", dco)
+    dcat = ops.conv_dgrad(dco, ws[5])
+    n4, h4, w4, c4 = a4.shape
+    da4 = ops.conv_dgrad(dcat[..., 0:q], ws[0])
+    conv_w("aspp.conv1.weight", ops.conv_wgrad(a4, dcat[..., 0:q], 1, 1))
+    bias_grad("aspp.conv1.bias", dcat[..., 0:q])
+    for i, d in enumerate((6, 12, 18)):
+        sl = dcat[..., (1 + i) * q:(2 + i) * q]
+        conv_w(f"aspp.conv{2 + i}.weight", ops.conv_general_wgrad(a4, sl, 3, 3, 1, d, d))
+        bias_grad(f"aspp.conv{2 + i}.bias", sl)
+        ops.conv_general_dgrad(sl, ws[1 + i], h4, w4, 1, d, d, out=da4, accumulate=True)
+    # image-pooling branch: d(x5)[n,c] = sum over pixels of the broadcast slice; then 1x1 conv backward; then the mean's backward
+    dx5 = torch.empty((n4, 1, 1, q), device=dev, dtype=torch.float32)
+    sl5 = dcat[..., 4 * q:]
+    mean_nc, m2_nc = sm.f(n4 * q), sm.f(n4 * q)
+    wsp = B._ws(n4, h4 * w4, q, dev)
+    check(lib.runet_chan_stats(sl5.data_ptr(), ops.ld(sl5), n4, h4 * w4, q, wsp.data_ptr(), mean_nc.data_ptr(), m2_nc.data_ptr(), None, None, None,
+                               None, 0, st))
+    # dx5 = mean * HW (sum over pixels): fold the HW factor into bn_apply-style scale
+    ones = torch.full((q,), float(h4 * w4), device=dev, dtype=torch.float32)
+    zeros = torch.zeros(q, device=dev, dtype=torch.float32)
+    B.bn_apply(mean_nc.view(n4, 1, 1, q), ones, zeros, None, relu=False, out=dx5)
+    conv_w("aspp.conv5.weight", ops.conv_wgrad(a["pooled4"], dx5, 1, 1))
+    bias_grad("aspp.conv5.bias", dx5)
+    dpooled = ops.conv_dgrad(dx5, ws[4])                                   # [n,1,1,512]; each pixel gets dpooled / HW
+    inv = torch.full((c4,), 1.0 / float(h4 * w4), device=dev, dtype=torch.float32)
+    dpool_s = ops.empty_nhwc(n4, 1, 1, c4, a4)
+    B.bn_apply(dpooled, inv, torch.zeros(c4, device=dev, dtype=torch.float32), None, relu=False, out=dpool_s)
+    bc = ops.empty_nhwc(n4, h4, w4, c4, a4)
+    check(lib.runet_broadcast_nc(dpool_s.data_ptr(), bc.data_ptr(), ops.ld(bc), n4, h4 * w4, c4, st))
+    # da4 += broadcast: reuse the accumulate path of a 1x1 identity?  simpler: bn_apply has no accumulate, so add through torch-free axpy:
+    # use conv_dgrad's accumulate with an identity is wasteful; instead finish with one elementwise kernel below
+    _add_inplace(da4, bc)
+    # ---- backbone
+    c = C["conv4"]
+    draw = bn_back("conv4.1", c, da4)
+    conv_w("conv4.0.weight", ops.conv_general_wgrad(c["x"], draw, 3, 3, 2, 1))
+    bias_grad("conv4.0.bias", draw)
+    d3 = ops.conv_general_dgrad(draw, c["w"], c["x"].shape[1], c["x"].shape[2], 2, 1)
+    c = C["conv3"]
+    draw = bn_back("conv3.1", c, d3)
+    conv_w("conv3.0.weight", ops.conv_general_wgrad(c["x"], draw, 3, 3, 2, 1))
+    bias_grad("conv3.0.bias", draw)
+    d2 = ops.conv_general_dgrad(draw, c["w"], c["x"].shape[1], c["x"].shape[2], 2, 1)
+    c = C["conv2"]
+    draw = bn_back("conv2.2", c, d2)
+    conv_w("conv2.1.weight", ops.conv_wgrad(c["x"], draw, 3, 3))
+    bias_grad("conv2.1.bias", draw)
+    dp = ops.conv_dgrad(draw, c["w"])
+    idx, h1, w1 = C["pool"]
+    da1 = ops.empty_nhwc(dp.shape[0], h1, w1, dp.shape[3], dp)
+    check(lib.runet_maxpool3s2_bwd(dp.data_ptr(), ops.ld(dp), idx.data_ptr(), da1.data_ptr(), ops.ld(da1), dp.shape[0], h1, w1, dp.shape[3], st))
+    c = C["conv1"]
+    draw = bn_back("conv1.1", c, da1)
+    conv_w("conv1.0.weight", ops.conv_general_wgrad(c["x"], draw, 7, 7, 2, 3, cin_w=3))
+    bias_grad("conv1.0.bias", draw)
+    return G
+
+
+def _add_inplace(dst, src):
+    """dst += src for two dense NHWC tensors, through the BN-apply kernel's affine form y = x*1 + 0 ... (no accumulate flag there), so use
+    the dedicated C entry point."""
+    n, h, w, c = dst.shape
+    check(lib.runet_add_inplace(dst.data_ptr(), src.data_ptr(), n * h * w * c, ops.stream()))
+
+
+class _DeepLabFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, net, names, *params):
+        prob, C = dl_forward(net, x, save=True)
+        ctx.C, ctx.net, ctx.names = C, net, names
+        return prob
+
+    @staticmethod
+    def backward(ctx, dprob):
+        if ctx.C is None:
+            raise RuntimeError("DeepLabV3Plus backward called twice")
+        G = dl_backward(ctx.net, ctx.C, dprob.contiguous())
+        ctx.C = None
+        return (None, None, None) + tuple(G[k] for k in ctx.names)

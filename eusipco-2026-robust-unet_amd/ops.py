@@ -257,3 +257,72 @@ def seg_counts(pred, target, threshold=0.5):
     counts = torch.empty((n, 4), device=pred.device, dtype=torch.int64)
     check(lib.runet_seg_counts(pred.data_ptr(), target.data_ptr(), counts.data_ptr(), n, per, float(threshold), stream()))
     return counts
+
+
+# ------------------------------------------------------------------------------- general geometry (DeepLabV3+ baseline)
+def conv_out_hw(h, w, k, stride, pad, dil):
+    return (h + 2 * pad - dil * (k - 1) - 1) // stride + 1, (w + 2 * pad - dil * (k - 1) - 1) // stride + 1
+
+
+def conv_general_fwd(x, w_hwio, bias, stride, pad, dil=1, out=None):
+    n, h, w, cin = x.shape
+    kh, kw, cin_w, cout = w_hwio.shape
+    ho, wo = conv_out_hw(h, w, kh, stride, pad, dil)
+    if out is None:
+        out = empty_nhwc(n, ho, wo, cout, x)
+    check(lib.runet_conv2d_general(x.data_ptr(), ld(x), w_hwio.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(),
+                                   ld(out), n, h, w, cin, cin_w, cout, kh, kw, stride, pad, dil, CONV_FWD, 0, stream()))
+    return out
+
+
+def conv_general_dgrad(dy, w_hwio, hin, win, stride, pad, dil=1, out=None, accumulate=False):
+    n, ho, wo, cout = dy.shape
+    kh, kw, cin, _ = w_hwio.shape
+    if out is None:
+        out = empty_nhwc(n, hin, win, cin, dy)
+    check(lib.runet_conv2d_general(dy.data_ptr(), ld(dy), w_hwio.data_ptr(), None, out.data_ptr(), ld(out), n, hin, win, cout, cout, cin,
+                                   kh, kw, stride, pad, dil, CONV_DGRAD, int(accumulate), stream()))
+    return out
+
+
+def conv_general_wgrad(x, dy, kh, kw, stride, pad, dil=1, cin_w=None, out=None):
+    n, h, w, cin = x.shape
+    cout = dy.shape[3]
+    cin_w = cin if cin_w is None else cin_w
+    if out is None:
+        out = torch.empty((kh, kw, cin_w, cout), device=x.device, dtype=torch.float32)
+    ws = workspace(lib.runet_conv_wgrad_general_workspace_floats(dy.shape[0] * dy.shape[1] * dy.shape[2], cin_w, cout, kh, kw), x.device)
+    check(lib.runet_conv_wgrad_general(x.data_ptr(), ld(x), dy.data_ptr(), ld(dy), out.data_ptr(), ws.data_ptr(), ws.numel(), n, h, w, cin, cin_w,
+                                       cout, kh, kw, stride, pad, dil, 0, stream()))
+    return out
+
+
+def convt4_fwd(x, w_hwio, bias, out=None):
+    n, h, w, cin = x.shape
+    cout = w_hwio.shape[3]
+    if out is None:
+        out = empty_nhwc(n, 2 * h, 2 * w, cout, x)
+    check(lib.runet_convt4_igemm(x.data_ptr(), ld(x), w_hwio.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(), ld(out),
+                                 n, h, w, cin, cout, CONVT_FWD, 0, stream()))
+    return out
+
+
+def convt4_dgrad(dy, w_hwio, out=None):
+    n, h2, w2, cout = dy.shape
+    cin = w_hwio.shape[2]
+    if out is None:
+        out = empty_nhwc(n, h2 // 2, w2 // 2, cin, dy)
+    check(lib.runet_convt4_igemm(dy.data_ptr(), ld(dy), w_hwio.data_ptr(), None, out.data_ptr(), ld(out), n, h2 // 2, w2 // 2, cout, cin,
+                                 CONVT_DGRAD, 0, stream()))
+    return out
+
+
+def convt4_wgrad(x, dy, out=None):
+    n, h, w, cin = x.shape
+    cout = dy.shape[3]
+    if out is None:
+        out = torch.empty((4, 4, cin, cout), device=x.device, dtype=torch.float32)
+    ws = workspace(lib.runet_conv_wgrad_general_workspace_floats(n * h * w, cin, cout, 4, 4), x.device)
+    check(lib.runet_conv_wgrad_general(x.data_ptr(), ld(x), dy.data_ptr(), ld(dy), out.data_ptr(), ws.data_ptr(), ws.numel(), n, h, w, cin, cin,
+                                       cout, 4, 4, 2, 1, 1, 1, stream()))
+    return out

@@ -165,6 +165,33 @@ int runet_adam_multi(const long long* table, int n_tensors, const int* chunks, i
 /* ---- ModelEvaluator.calculate_metrics counts (Main_Final.py:519-547): counts[n] = {tp, pred>thr, target!=0, agree} ---- */
 int runet_seg_counts(const float* pred, const float* target, long long* counts, int n_img, long per_img, float threshold, void* stream);
 
+/* ---- DeepLabV3+ baseline (Main_Final.py:325-433): the same implicit-GEMM kernels with general geometry ----
+ * runet_conv2d_general: Conv2d(kh x kw <= 7x7, stride 1|2, padding, dilation).  mode RUNET_CONV_FWD: x [n,hin,win,cin] -> y [n,ho,wo,cout],
+ * w [kh,kw,cin_w,cout];  mode RUNET_CONV_DGRAD: x := dy [n,ho,wo,cin(=conv Cout)] -> y := dx [n,hin,win,cout(=conv Cin)], w [kh,kw,cout,cin].
+ * runet_convt4_igemm: ConvTranspose2d(k4, s2, p1), w [4,4,cin,cout]; RUNET_CONVT_FWD x [n,h,w,cin] -> y [n,2h,2w,cout];
+ * RUNET_CONVT_DGRAD x := dy [n,2h,2w,cin(=Cout)] -> y := dx [n,h,w,cout(=Cin)].
+ * runet_conv_wgrad_general: dw of either (transposed4 != 0: the k4 transposed conv, x [n,hin,win,cin], dy [n,2hin,2win,cout]). */
+int runet_conv2d_general(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int n_img, int hin, int win, int cin,
+                         int cin_w, int cout, int kh, int kw, int stride, int pad, int dil, int mode, int accumulate, void* stream);
+int runet_convt4_igemm(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int n_img, int h, int w_, int cin, int cout,
+                       int mode, int accumulate, void* stream);
+long runet_conv_wgrad_general_workspace_floats(int pixels, int cin_w, int cout, int kh, int kw);
+int runet_conv_wgrad_general(const float* x, int ldx, const float* dy, int ldy, float* dw, float* workspace, long workspace_floats, int n_img,
+                             int hin, int win, int cin, int cin_w, int cout, int kh, int kw, int stride, int pad, int dil, int transposed4,
+                             void* stream);
+/* MaxPool2d(3, stride 2, padding 1) (Main_Final.py:369); idx: one byte per output element (window position of the first maximum) */
+int runet_maxpool3s2_fwd(const float* x, int ldx, float* y, int ldy, unsigned char* idx, int n_img, int h, int w, int c, void* stream);
+int runet_maxpool3s2_bwd(const float* dy, int lddy, const unsigned char* idx, float* dx, int lddx, int n_img, int h, int w, int c, void* stream);
+/* dst[i] += src[i] (dense buffers): joins the ASPP image-pooling gradient with the other four branches' */
+int runet_add_inplace(float* dst, const float* src, long n, void* stream);
+/* y[n, p, 0:c] = v[n, 0:c]: bilinear upsampling of the ASPP image-pooling branch's 1x1 map (Main_Final.py:350-352) */
+int runet_broadcast_nc(const float* v_nc, float* y, int ldy, int n_img, int hw, int c, void* stream);
+/* decoder head Conv2d(c, 1, 3, padding 1) + sigmoid (Main_Final.py:414,433); w [3,3,c] ; dw_db = [9*c] weight gradient then the bias gradient */
+int runet_head3x3_fwd(const float* x, int ld, const float* w, const float* b, float* prob, int n_img, int h, int w_, int c, void* stream);
+long runet_head3x3_bwd_workspace_floats(int n_img, int h, int w_, int c);
+int runet_head3x3_bwd(const float* dprob, const float* prob, const float* x, int ld, const float* w, float* dx, int lddx, float* workspace,
+                      float* dw_db, int n_img, int h, int w_, int c, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

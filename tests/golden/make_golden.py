@@ -139,6 +139,50 @@ def model_case(base, n, size, seed, tag):
     print(tag, "loss", loss.item(), "iou", out["eval_metric/iou"])
 
 
+def deeplab_case(n, size, seed, tag):
+    """DeepLabV3+ baseline (Main_Final.py:325-433) train step + eval forward through the reference class."""
+    dl = importlib.import_module("oracle.deeplab_ref")
+    out = {}
+    model = ref.DeepLabV3Plus(n_classes=1)
+    st = dl.init_state(seed=seed, perturb_bn=True)
+    res = model.load_state_dict(st, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    x, y = pkg_data.synthetic_batch(n, size, seed=seed)
+    model.train()
+    taps, hooks = {}, []
+    for name in ("conv1", "conv2", "conv3", "conv4", "aspp", "decoder.2", "decoder.5", "decoder.8", "decoder.11", "decoder.12"):
+        hooks.append(get_sub(model, name).register_forward_hook(lambda m, i, o, name=name: taps.__setitem__(name, o.detach().clone())))
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-4)
+    opt.zero_grad()
+    prob = model(x)
+    loss = torch.nn.BCELoss()(prob, y)
+    loss.backward()
+    for h in hooks:
+        h.remove()
+    put(out, "prob", prob, full=True)
+    for k, v in taps.items():
+        put(out, "tap/" + k, v)
+    out["loss"] = np.array(loss.item(), dtype=np.float64)
+    names = [k for k, _ in model.named_parameters()]
+    out["grad_norm"] = np.array([p.grad.double().norm().item() for _, p in model.named_parameters()])
+    for k, p in model.named_parameters():
+        put(out, "grad/" + k, p.grad, full=p.numel() <= 4096)
+    for k, b in model.named_buffers():
+        if not k.endswith("num_batches_tracked"):
+            put(out, "buf/" + k, b, full=True)
+    opt.step()
+    out["param_delta_abs_sum"] = np.array([(p.detach().double() - st[k].double()).abs().sum().item() for k, p in model.named_parameters()])
+    model.eval()
+    with torch.no_grad():
+        pe = model(x)
+    put(out, "eval_prob", pe, full=True)
+    np.savez_compressed(os.path.join(HERE, f"deeplab_{tag}.npz"), **out)
+    with open(os.path.join(HERE, f"deeplab_{tag}.json"), "w") as f:
+        json.dump({"n": n, "size": size, "seed": seed, "param_names": names,
+                   "state_dict": [[k, list(v.shape), str(v.dtype)] for k, v in model.state_dict().items()],
+                   "n_params": sum(p.numel() for p in model.parameters())}, f, indent=1)
+
+
 def state_dict_case():
     model = ref.RobustUNet()
     sd = model.state_dict()
@@ -259,8 +303,14 @@ def labelme_cases():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "deeplab":
+        deeplab_case(n=2, size=64, seed=7, tag="n2_s64")
+        deeplab_case(n=2, size=128, seed=9, tag="n2_s128")
+        sys.exit(0)
     state_dict_case()
     labelme_cases()
     block_cases()
     model_case(base=16, n=2, size=64, seed=3, tag="b16_n2_s64")
     model_case(base=64, n=2, size=64, seed=5, tag="b64_n2_s64")
+    deeplab_case(n=2, size=64, seed=7, tag="n2_s64")
+    deeplab_case(n=2, size=128, seed=9, tag="n2_s128")

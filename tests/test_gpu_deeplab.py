@@ -1,0 +1,187 @@
+"""GPU: general-geometry convolution entry points against torch CPU ops, and the DeepLabV3+ baseline train step through the C ABI
+against goldens captured from the reference (tests/golden/deeplab_*.npz).  Tolerances: fp32 1e-3 (north_star)."""
+import importlib
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import GOLDEN, PKG_NAME, load_npz, sampled
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    return importlib.import_module(PKG_NAME + ".ops")
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous().to(DEV)
+
+
+def close(got_nhwc, ref_nchw, tol=1e-3, msg=""):
+    got = got_nhwc.permute(0, 3, 1, 2).cpu().numpy()
+    ref = ref_nchw.detach().numpy()
+    np.testing.assert_allclose(got, ref, rtol=tol, atol=tol * max(1e-6, float(np.abs(ref).max())), err_msg=msg)
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout,k,stride,pad,dil", [
+    (2, 32, 32, 3, 64, 7, 2, 3, 1),     # stem (cin padded to 4 in memory, 3 in the weight)
+    (2, 16, 16, 64, 128, 3, 2, 1, 1),
+    (3, 12, 20, 32, 48, 3, 2, 1, 1),    # ragged tiles
+    (2, 8, 8, 128, 64, 3, 1, 6, 6),
+    (2, 16, 16, 64, 64, 3, 1, 12, 12),
+    (1, 24, 24, 32, 32, 3, 1, 18, 18),
+    (2, 4, 4, 512, 256, 3, 1, 18, 18),  # only the centre tap is in bounds
+])
+def test_conv2d_general(ops, n, h, w, cin, cout, k, stride, pad, dil):
+    g = torch.Generator().manual_seed(n * 1000 + h + cin + k + dil)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    b = torch.randn(cout, generator=g)
+    x.requires_grad_(True)
+    wt.requires_grad_(True)
+    y = F.conv2d(x, wt, b, stride, pad, dil)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    cin_p = (cin + 3) // 4 * 4
+    xd = torch.zeros(n, h, w, cin_p, device=DEV)
+    xd[..., :cin] = nhwc(x.detach())
+    wd = wt.detach().permute(2, 3, 1, 0).contiguous().to(DEV)                    # [k,k,cin,cout]
+    got = ops.conv_general_fwd(xd, wd, b.to(DEV), stride, pad, dil)
+    close(got, y, msg="fwd")
+    dyd = nhwc(dy)
+    dwg = ops.conv_general_wgrad(xd, dyd, k, k, stride, pad, dil, cin_w=cin)
+    ref_dw = wt.grad.permute(2, 3, 1, 0).numpy()
+    np.testing.assert_allclose(dwg.cpu().numpy(), ref_dw, rtol=1e-3, atol=1e-3 * float(np.abs(ref_dw).max()), err_msg="wgrad")
+    if cin % 4 == 0:
+        dx = ops.conv_general_dgrad(dyd, wd, h, w, stride, pad, dil)
+        close(dx, x.grad, msg="dgrad")
+        base = torch.randn(n, h, w, cin, generator=g).to(DEV)
+        acc = base.clone()
+        ops.conv_general_dgrad(dyd, wd, h, w, stride, pad, dil, out=acc, accumulate=True)
+        close(acc - base, x.grad, tol=2e-3, msg="dgrad accumulate")
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout", [(2, 4, 4, 256, 128), (2, 8, 8, 128, 64), (3, 6, 10, 64, 32), (2, 32, 32, 32, 16)])
+def test_convtranspose_k4s2p1(ops, n, h, w, cin, cout):
+    g = torch.Generator().manual_seed(n + h + cin)
+    x = torch.randn(n, cin, h, w, generator=g, requires_grad=True)
+    wt = (torch.randn(cin, cout, 4, 4, generator=g) / (cin * 4) ** 0.5).requires_grad_(True)
+    b = torch.randn(cout, generator=g)
+    y = F.conv_transpose2d(x, wt, b, stride=2, padding=1)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    wd = wt.detach().permute(2, 3, 0, 1).contiguous().to(DEV)                    # [4,4,cin,cout]
+    xd, dyd = nhwc(x.detach()), nhwc(dy)
+    close(ops.convt4_fwd(xd, wd, b.to(DEV)), y, msg="fwd")
+    close(ops.convt4_dgrad(dyd, wd), x.grad, msg="dgrad")
+    ref_dw = wt.grad.permute(2, 3, 0, 1).numpy()
+    np.testing.assert_allclose(ops.convt4_wgrad(xd, dyd).cpu().numpy(), ref_dw, rtol=1e-3, atol=1e-3 * float(np.abs(ref_dw).max()), err_msg="wgrad")
+
+
+def test_maxpool3s2_and_head(ops):
+    lib = importlib.import_module(PKG_NAME + "._lib").lib
+    check = importlib.import_module(PKG_NAME + "._lib").check
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 64, 18, 22, generator=g, requires_grad=True)
+    y = F.max_pool2d(x, 3, 2, 1)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    xd = nhwc(x.detach())
+    n, h, w, c = xd.shape
+    ho, wo = y.shape[2], y.shape[3]
+    yd = torch.empty(n, ho, wo, c, device=DEV)
+    idx = torch.empty(n, ho, wo, c, device=DEV, dtype=torch.uint8)
+    check(lib.runet_maxpool3s2_fwd(xd.data_ptr(), c, yd.data_ptr(), c, idx.data_ptr(), n, h, w, c, ops.stream()))
+    close(yd, y, tol=0, msg="pool fwd")
+    dxd = torch.empty_like(xd)
+    dyd = nhwc(dy)
+    check(lib.runet_maxpool3s2_bwd(dyd.data_ptr(), c, idx.data_ptr(), dxd.data_ptr(), c, n, h, w, c, ops.stream()))
+    close(dxd, x.grad, tol=1e-6, msg="pool bwd")
+    # head: Conv2d(16,1,3,p1) + sigmoid
+    x = torch.randn(2, 16, 20, 24, generator=g, requires_grad=True)
+    wt = (torch.randn(1, 16, 3, 3, generator=g) * 0.2).requires_grad_(True)
+    b = torch.randn(1, generator=g).requires_grad_(True)
+    p = torch.sigmoid(F.conv2d(x, wt, b, 1, 1))
+    dp = torch.randn(p.shape, generator=g)
+    p.backward(dp)
+    xd = nhwc(x.detach())
+    wd = wt.detach().permute(2, 3, 1, 0).contiguous().to(DEV)
+    n, h, w, c = xd.shape
+    pd = torch.empty(n, 1, h, w, device=DEV)
+    check(lib.runet_head3x3_fwd(xd.data_ptr(), c, wd.data_ptr(), b.detach().to(DEV).data_ptr(), pd.data_ptr(), n, h, w, c, ops.stream()))
+    np.testing.assert_allclose(pd.cpu().numpy(), p.detach().numpy(), rtol=0, atol=1e-5)
+    dxd = torch.empty_like(xd)
+    ws = torch.empty(lib.runet_head3x3_bwd_workspace_floats(n, h, w, c), device=DEV)
+    dwdb = torch.empty(9 * c + 1, device=DEV)
+    check(lib.runet_head3x3_bwd(dp.to(DEV).data_ptr(), pd.data_ptr(), xd.data_ptr(), c, wd.data_ptr(), dxd.data_ptr(), c, ws.data_ptr(), dwdb.data_ptr(),
+                                n, h, w, c, ops.stream()))
+    close(dxd, x.grad, msg="head dx")
+    ref = np.concatenate([wt.grad.permute(2, 3, 1, 0).reshape(-1).numpy(), b.grad.numpy()])
+    np.testing.assert_allclose(dwdb.cpu().numpy(), ref, rtol=1e-3, atol=1e-3 * float(np.abs(ref).max()))
+
+
+@pytest.mark.parametrize("tag", ["n2_s64", "n2_s128"])
+def test_deeplab_train_step_matches_reference(pkg, tag):
+    dl = importlib.import_module("oracle.deeplab_ref")
+    with open(os.path.join(GOLDEN, f"deeplab_{tag}.json")) as f:
+        meta = json.load(f)
+    gold = load_npz(f"deeplab_{tag}.npz")
+    model = pkg.DeepLabV3Plus(n_classes=1)
+    st = dl.init_state(seed=meta["seed"], perturb_bn=True)
+    res = model.load_state_dict(st, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    model = model.to(DEV)
+    assert [[k, list(v.shape), str(v.dtype)] for k, v in model.state_dict().items()] == meta["state_dict"]
+    x, y = pkg.synthetic_batch(meta["n"], meta["size"], seed=meta["seed"])
+    x, y = x.to(DEV), y.to(DEV)
+    model.train()
+    opt = pkg.FusedAdam(model.parameters(), lr=1e-4, weight_decay=1e-4)
+    opt.zero_grad()
+    prob = model(x)
+    loss = pkg.bce_loss(prob, y)
+    loss.backward()
+    np.testing.assert_allclose(prob.detach().cpu().numpy(), gold["prob"], rtol=0, atol=1e-3)
+    assert abs(loss.item() - float(gold["loss"])) <= 1e-3
+    names = meta["param_names"]
+    gn = np.array([p.grad.double().norm().item() for _, p in model.named_parameters()])
+    ref = gold["grad_norm"]
+    zero_bias = {"conv1.0.bias", "conv2.1.bias", "conv3.0.bias", "conv4.0.bias", "aspp.conv_out.bias", "decoder.0.bias", "decoder.3.bias",
+                 "decoder.6.bias", "decoder.9.bias"}
+    for i, k in enumerate(names):
+        if k in zero_bias:      # conv bias feeding a train-mode BN: analytically zero
+            assert ref[i] <= 1e-4 * ref.max() and gn[i] <= 1e-4 * ref.max(), k
+            continue
+        assert abs(gn[i] - ref[i]) <= 2e-2 * ref[i] + 1e-4 * ref.max(), (k, gn[i], ref[i])
+    for k, p in model.named_parameters():
+        if k in zero_bias:
+            continue
+        g = p.grad
+        if f"grad/{k}" in gold:
+            gr = gold[f"grad/{k}"]
+            np.testing.assert_allclose(g.cpu().numpy(), gr, rtol=1e-2, atol=1e-2 * float(np.abs(gr).max()) + 1e-9, err_msg=k)
+        else:
+            gr = gold[f"grad/{k}/sample"]
+            np.testing.assert_allclose(sampled(g.contiguous(), gold[f"grad/{k}/meta"]), gr, rtol=1e-2, atol=1e-2 * float(np.abs(gr).max()) + 1e-9,
+                                       err_msg=k)
+    for k, b in model.named_buffers():
+        if not k.endswith("num_batches_tracked"):
+            np.testing.assert_allclose(b.cpu().numpy(), gold[f"buf/{k}"], rtol=1e-3, atol=1e-4, err_msg=k)
+        else:
+            assert b.item() == 1
+    before = {k: p.detach().clone() for k, p in model.named_parameters()}
+    opt.step()
+    delta = np.array([(p.detach().double() - before[k].double()).abs().sum().item() for k, p in model.named_parameters()])
+    refd = gold["param_delta_abs_sum"]
+    ok = np.array([k not in zero_bias for k in names])
+    np.testing.assert_allclose(delta[ok], refd[ok], rtol=2e-2, atol=1e-6)
+    model.eval()
+    with torch.no_grad():
+        pe = model(x)
+    np.testing.assert_allclose(pe.cpu().numpy(), gold["eval_prob"], rtol=0, atol=2e-3)
