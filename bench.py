@@ -106,8 +106,13 @@ def main():
     dev_index = 0 if one_device else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    # RUNET_BENCH_FORCE_DIST=1: exercise the RCCL path (process group, bucketed all-reduce on the side stream) with a single rank
+    use_dist = world > 1 or os.environ.get("RUNET_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -118,7 +123,7 @@ def main():
     torch.manual_seed(1234 + rank)             # dropout draws differ per rank
     model = pkg.RobustUNet(3, 1, args.base).to(dev).train()
     sync = None
-    if world > 1:
+    if use_dist:
         sync = pkg.GradAllReducer(model, sync_bn=args.sync_bn)
         sync.broadcast_parameters(0)
     step = pkg.TrainStep(model, lr=1e-4, weight_decay=1e-4, grad_sync=sync)
@@ -127,7 +132,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -147,7 +152,7 @@ def main():
     dt = time.perf_counter() - t0
     roof = None if prof is None else ops.stop_conv_profile(prof)
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     final_loss = float(loss.item())
@@ -187,7 +192,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.size, 1234)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

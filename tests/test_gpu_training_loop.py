@@ -53,3 +53,19 @@ def test_train_evaluate_and_checkpoint_loops(pkg, oracle, tmp_path):
         p_dev = m2(x.to(dev)).cpu()
         p_ref, _ = oracle.forward({k: v.clone() for k, v in ck.items()}, x, training=False)
     np.testing.assert_allclose(p_dev.numpy(), p_ref.numpy(), rtol=0, atol=1e-3)
+
+
+def test_deeplab_baseline_trains_through_the_same_evaluator(pkg, tmp_path):
+    """Main_Final.py:841-871 runs every model of its dict through the same ModelEvaluator; config 4 of BASELINE.json."""
+    dev = torch.device("cuda:0")
+    d = str(tmp_path)
+    _dataset(d)
+    train, val = pkg.prepare_dataset(os.path.join(d, "img"), os.path.join(d, "ann"), batch_size=4, image_size=(64, 64))
+    torch.manual_seed(0)
+    model = pkg.DeepLabV3Plus(n_classes=1).to(dev)
+    ev = pkg.ModelEvaluator(dev)
+    out = ev.train_model(model, train, val, epochs=4, lr=1e-3)
+    h = out["history"]
+    assert len(h["train_loss"]) == 4 and all(np.isfinite(h["train_loss"])) and h["train_loss"][-1] < h["train_loss"][0]
+    res = ev.evaluate_model(model, val)
+    assert res["total_samples"] == 2 and 0.0 <= res["mean_iou"] <= 1.0
