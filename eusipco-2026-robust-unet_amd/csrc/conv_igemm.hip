@@ -39,6 +39,8 @@ struct IGemmArgs {
     int a_div;                    // >1: source coordinate must be divisible by a_div and is divided by it (data gradient of a strided conv)
     int zmode4;                   // 1: ConvTranspose2d(k4,s2,p1) forward: blockIdx.z = output parity class (ph,pw); taps (a,b) in 2x2 read
                                   //    weight tap (1-ph+2a, 1-pw+2b) of the 4x4 filter at source offset (ph-a, pw-b)
+    long zs_x, zs_w, zs_y;        // zbatch: blockIdx.z selects one GEMM of a batch (element strides of x, w and y)
+    int zbatch;
 };
 
 template <int BM, int BN, int WM, int WN, bool KCONTIG>
@@ -66,8 +68,11 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IGemmArgs g) {
     const int HW = g.H * g.W;
 
     const float* wbase = g.w;
+    const float* xb = g.x;
+    float* yb = g.y;
+    if (g.zbatch) { xb += (long)blockIdx.z * g.zs_x; wbase += (long)blockIdx.z * g.zs_w; yb += (long)blockIdx.z * g.zs_y; }
     int o_dh = g.o_dh, o_dw = g.o_dw;
-    const int ph4 = blockIdx.z >> 1, pw4 = blockIdx.z & 1;
+    const int ph4 = (blockIdx.z >> 1) & 1, pw4 = blockIdx.z & 1;
     if (g.zmode4) { o_dh = ph4; o_dw = pw4; }
     if (g.z_taps > 0) {
         wbase += (long)blockIdx.z * g.w_tap_stride;
@@ -116,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IGemmArgs g) {
             }
             ok = ok && (unsigned)ih < (unsigned)g.Hin && (unsigned)iw < (unsigned)g.Win;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) v = *reinterpret_cast<const f32x4*>(g.x + ((a_img[i] + (long)ih * g.Win + iw) * g.ldx + kofs + akq * 4));
+            if (ok) v = *reinterpret_cast<const f32x4*>(xb + ((a_img[i] + (long)ih * g.Win + iw) * g.ldx + kofs + akq * 4));
             ra[i] = v;
         }
         const float* wt = wbase + (long)wtap * g.w_tap_stride;
@@ -253,7 +258,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IGemmArgs g) {
                     const int h = rem / g.W, w = rem - h * g.W;
                     op = ((long)nimg * g.Hout + (h * g.o_scale + o_dh)) * g.Wout + (w * g.o_scale + o_dw);
                 }
-                drow[i] = p < P ? g.y + op * g.ldy : nullptr;
+                drow[i] = p < P ? yb + op * g.ldy : nullptr;
 #pragma unroll
                 for (int b = 0; b < TN; ++b) old[i][b] = (g.accumulate && drow[i] && ncol[b] < g.Ncols) ? drow[i][ncol[b]] : 0.f;
             }
@@ -281,6 +286,7 @@ struct WGradArgs {
     int tap_on_output;           // 1: tap (r,s) offsets the dy pixel (transposed conv), x pixel unshifted
     int o_bh, o_bw;              // base offset of the dy pixel when tap_on_output (k4-s2-p1 transposed conv: -1)
     long pix_per_split;          // multiple of 16
+    long tap_bs_x, tap_bs_dy;    // batched form: tap t reads x + t*tap_bs_x and dy + t*tap_bs_dy (no spatial shift)
 };
 
 template <int BM, int BN, int WM, int WN>
@@ -310,6 +316,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WGradArgs g) {
     int xdh = g.bh, xdw = g.bw, ydh = 0, ydw = 0;
     if (g.tap_on_output) { ydh = tr + g.o_bh; ydw = ts + g.o_bw; } else { xdh += tr * g.tdh; xdw += ts * g.tdw; }
 
+    const float* xb = g.x + (long)tap * g.tap_bs_x;
+    const float* dyb = g.dy + (long)tap * g.tap_bs_dy;
     f32x4 ra[AREGS], rb[BREGS];
     auto load_tile = [&](long pk) {   // pk: first pixel of the 16-pixel k-step
 #pragma unroll
@@ -323,7 +331,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WGradArgs g) {
                 const int h = rem / g.W, w = rem - h * g.W;
                 const int ih = h * g.a_scale + xdh, iw = w * g.a_scale + xdw;
                 if ((unsigned)ih < (unsigned)g.Hin && (unsigned)iw < (unsigned)g.Win)
-                    v = *reinterpret_cast<const f32x4*>(g.x + (((long)n * g.Hin + ih) * g.Win + iw) * g.ldx + ci0 + cq * 4);
+                    v = *reinterpret_cast<const f32x4*>(xb + (((long)n * g.Hin + ih) * g.Win + iw) * g.ldx + ci0 + cq * 4);
             }
             ra[i] = v;
         }
@@ -338,7 +346,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WGradArgs g) {
                 const int h = rem / g.W, w = rem - h * g.W;
                 const int oh = h * g.o_scale + ydh, ow = w * g.o_scale + ydw;
                 if ((unsigned)oh < (unsigned)g.Hout && (unsigned)ow < (unsigned)g.Wout)
-                    v = *reinterpret_cast<const f32x4*>(g.dy + (((long)n * g.Hout + oh) * g.Wout + ow) * g.ldy + co0 + cq * 4);
+                    v = *reinterpret_cast<const f32x4*>(dyb + (((long)n * g.Hout + oh) * g.Wout + ow) * g.ldy + co0 + cq * 4);
             }
             rb[i] = v;
         }
@@ -1010,5 +1018,50 @@ extern "C" int runet_conv_wgrad_general(const float* x, int ldx, const float* dy
     if (big) hipLaunchKernelGGL((wgrad_kernel<128, 128, 64, 64>), grid, dim3(256), 2 * (16 * (128 + 4) * 2) * sizeof(float), st, a);
     else hipLaunchKernelGGL((wgrad_kernel<64, 64, 32, 32>), grid, dim3(256), 2 * (16 * (64 + 4) * 2) * sizeof(float), st, a);
     if (splits > 1) hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(wsize, 32 * 4)), dim3(256), 0, st, workspace, dw, wsize, splits);
+    RUNET_CHECK_LAUNCH();
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Batched plain GEMMs on the same kernels (the 36 position-GEMMs of the unfused Winograd F(4x4,3x3) path, conv_winograd4.hip).
+//   runet_gemm_batched   : C[z][rows][n] = A[z][rows][k] . B[z][k][n]                (blockIdx.z = z)
+//   runet_gemm_tn_batched: C[split][z][k][n] = sum over the split's rows of A[z][row][k] * B[z][row][n];  splits = ceil(rows / rows_per_split)
+extern "C" int runet_gemm_batched(const float* a, int lda, long stride_a, const float* b, long stride_b, float* c, int ldc, long stride_c,
+                                  int batch, int rows, int k, int n, void* stream) {
+    RUNET_REQUIRE(a && b && c && batch > 0 && batch <= 65535 && rows > 0, "bad arguments");
+    RUNET_REQUIRE(k > 0 && k % 4 == 0 && n > 0 && n % 4 == 0 && lda >= k && lda % 4 == 0 && ldc >= n && ldc % 4 == 0, "k, n and the row strides must be multiples of 4");
+    RUNET_REQUIRE(((uintptr_t)a % 16) == 0 && ((uintptr_t)b % 16) == 0 && ((uintptr_t)c % 16) == 0 && stride_a % 4 == 0 && stride_b % 4 == 0 && stride_c % 4 == 0,
+                  "alignment");
+    IGemmArgs g{};
+    g.x = a; g.ldx = lda; g.w = b; g.y = c; g.ldy = ldc; g.K = (k + 15) / 16 * 16; g.Kx = k; g.Kvalid = k; g.Ncols = n;
+    g.w_sk = n; g.w_sn = 1; g.Nimg = 1; g.H = 1; g.W = rows; g.Hin = 1; g.Win = rows; g.a_scale = 1; g.KH = 1; g.KW = 1;
+    g.Hout = 1; g.Wout = rows; g.o_scale = 1; g.zbatch = 1; g.zs_x = stride_a; g.zs_w = stride_b; g.zs_y = stride_c;
+    hipStream_t st = (hipStream_t)stream;
+    const long b128 = (long)cdiv(rows, 128) * cdiv(n, 128) * batch;
+    if (n % 128 == 0 && b128 >= 256) launch_igemm<128, 128, 64, 64, false>(g, batch, st);
+    else if (n > 32 && (long)cdiv(rows, 128) * cdiv(n, 64) * batch >= 256) launch_igemm<128, 64, 64, 32, false>(g, batch, st);
+    else if (n > 32) launch_igemm<64, 64, 32, 32, false>(g, batch, st);
+    else launch_igemm<128, 32, 32, 32, false>(g, batch, st);
+    RUNET_CHECK_LAUNCH();
+}
+
+extern "C" int runet_gemm_tn_batched(const float* a, int lda, long stride_a, const float* b, int ldb, long stride_b, float* c, int batch, int rows,
+                                     int k, int n, int rows_per_split, void* stream) {
+    RUNET_REQUIRE(a && b && c && batch > 0 && batch <= 65535 && rows > 0 && rows_per_split > 0 && rows_per_split % 16 == 0, "bad arguments (rows_per_split: multiple of 16)");
+    const int splits = cdiv(rows, rows_per_split);
+    RUNET_REQUIRE(splits <= 65535, "too many splits");
+    RUNET_REQUIRE(k > 0 && k % 4 == 0 && n > 0 && n % 4 == 0 && lda >= k && lda % 4 == 0 && ldb >= n && ldb % 4 == 0, "k, n and the row strides must be multiples of 4");
+    RUNET_REQUIRE(((uintptr_t)a % 16) == 0 && ((uintptr_t)b % 16) == 0 && ((uintptr_t)c % 16) == 0 && stride_a % 4 == 0 && stride_b % 4 == 0, "alignment");
+    WGradArgs g{};
+    g.x = a; g.ldx = lda; g.dy = b; g.ldy = ldb; g.out = c; g.Kci = k; g.Kvalid = k; g.Nco = n;
+    g.Nimg = 1; g.H = 1; g.W = rows; g.Hin = 1; g.Win = rows; g.a_scale = 1; g.KH = batch; g.KW = 1; g.Hout = 1; g.Wout = rows; g.o_scale = 1;
+    g.tap_bs_x = stride_a; g.tap_bs_dy = stride_b;
+    g.pix_per_split = rows_per_split;
+    hipStream_t st = (hipStream_t)stream;
+    const bool big = k > 64 && n > 64;
+    const int tiles = big ? cdiv(k, 128) * cdiv(n, 128) : cdiv(k, 64) * cdiv(n, 64);
+    dim3 grid(tiles, batch, splits);
+    if (big) hipLaunchKernelGGL((wgrad_kernel<128, 128, 64, 64>), grid, dim3(256), 2 * (16 * (128 + 4) * 2) * sizeof(float), st, g);
+    else hipLaunchKernelGGL((wgrad_kernel<64, 64, 32, 32>), grid, dim3(256), 2 * (16 * (64 + 4) * 2) * sizeof(float), st, g);
     RUNET_CHECK_LAUNCH();
 }

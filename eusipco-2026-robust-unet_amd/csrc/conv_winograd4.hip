@@ -1,0 +1,276 @@
+// Winograd F(4x4, 3x3) for the DEEP 3x3 convolutions (>= 256 channels at <= 64x64 pixels per image: down2/down3/bottleneck.2/
+// dec4/dec3 of /root/reference/Main_Final.py:235-270 and their autograd): 4x fewer multiplies than the direct convolution
+// (36 per 4x4 output tile and channel pair instead of 144), 1.78x fewer than the fused F(2x2,3x3) kernel of conv_winograd.hip.
+//
+//   Y = A^T [ (G g G^T) .* (B^T d B) ] A          6x6 input patch d (stride 4, 1-pixel halo), 3x3 filter g, 4x4 output tile
+//
+// Unfused on purpose: at these depths the Winograd-domain tensors are small next to the arithmetic (V = 2.25x the input, a few
+// tens of MB), so three streaming passes cost little, while the 36 position-GEMMs [tiles x K] x [K x N] run on the LDS-tiled
+// 128x128 MFMA GEMM (runet_gemm_batched) instead of a kernel that also has to transform.  The high-resolution layers (64/128
+// channels) stay on the fused F(2x2) kernel, where the Winograd-domain traffic would dominate.
+//   wino4_input_kernel<0>: V[36][T][C]  = B^T d B        wino4_input_kernel<1>: Z[36][T][C] = A dY A^T   (weight gradient)
+//   wino4_output_kernel  : y = A^T M A (+ bias, + y)
+//   wino4_weight_kernel  : U[36][K][N]  = G g G^T   (forward: g = w[.,.,k,n]; data gradient: g = rot180(w)[.,.,n,k])
+//   wino4_wgrad_out_kernel: dw = G^T (sum_splits dU) G
+// Interpolation points 0, +-1, +-2, inf (Lavin & Gray); fp32 throughout, error ~1e-5 relative to the direct convolution.
+#include "runet_common.h"
+#include "../../include/runet_hip.h"
+
+namespace {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <typename T> __device__ __forceinline__ void bt6(T& d0, T& d1, T& d2, T& d3, T& d4, T& d5) {     // B^T d (in place)
+    const T a = d4 - 4.f * d2, b = d3 - 4.f * d1, c = d4 - d2, e = 2.f * (d3 - d1);
+    const T t0 = 4.f * d0 - 5.f * d2 + d4, t5 = 4.f * d1 - 5.f * d3 + d5;
+    d0 = t0; d1 = a + b; d2 = a - b; d3 = c + e; d4 = c - e; d5 = t5;
+}
+template <typename T> __device__ __forceinline__ void a6(const T y0, const T y1, const T y2, const T y3, T (&z)[6]) {   // A y  (A = (A^T)^T, 6x4)
+    const T p = y0 + y2, q = y1 + y3, r = y0 + 4.f * y2, s = 2.f * y1 + 8.f * y3;
+    z[0] = y0; z[1] = p + q; z[2] = p - q; z[3] = r + s; z[4] = r - s; z[5] = y3;
+}
+template <typename T> __device__ __forceinline__ void at4(const T m0, const T m1, const T m2, const T m3, const T m4, const T m5, T (&o)[4]) {   // A^T m
+    const T p = m1 + m2, q = m1 - m2, r = m3 + m4, s = m3 - m4;
+    o[0] = m0 + p + r; o[1] = q + 2.f * s; o[2] = p + 4.f * r; o[3] = q + 8.f * s + m5;
+}
+
+struct W4Geom { int n_img, H, W, TY, TX; long T; };
+
+// MODE 0: src = conv input (or dy for the data gradient), 6x6 patch at (4ty-1, 4tx-1);  MODE 1: src = dy, 4x4 tile at (4ty, 4tx)
+template <int MODE>
+__global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restrict__ src, int ld, int C, W4Geom g, float* __restrict__ V) {
+    const int C2 = C >> 1;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= g.T * C2) return;
+    const long tile = idx / C2;
+    const int c = (int)(idx - tile * C2) * 2;
+    const int per = g.TY * g.TX;
+    const int n = (int)(tile / per);
+    const int rem = (int)(tile - (long)n * per);
+    const int ty = rem / g.TX, tx = rem - ty * g.TX;
+    f32x2 d[6][6];
+    if constexpr (MODE == 0) {
+        const int h0 = 4 * ty - 1, w0 = 4 * tx - 1;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int ih = h0 + i, iw = w0 + j;
+                const bool ok = (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
+                const long off = ok ? (((long)n * g.H + ih) * g.W + iw) * ld + c : 0;
+                const f32x2 v = *reinterpret_cast<const f32x2*>(src + off);
+                d[i][j] = ok ? v : f32x2{0.f, 0.f};
+            }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) bt6(d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j]);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) bt6(d[i][0], d[i][1], d[i][2], d[i][3], d[i][4], d[i][5]);
+    } else {
+        f32x2 y[4][4], t[6][4];
+        const float* base = src + (((long)n * g.H + 4 * ty) * g.W + 4 * tx) * ld + c;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y[i][j] = *reinterpret_cast<const f32x2*>(base + ((long)i * g.W + j) * ld);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x2 z[6];
+            a6(y[0][j], y[1][j], y[2][j], y[3][j], z);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) t[i][j] = z[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) a6(t[i][0], t[i][1], t[i][2], t[i][3], d[i]);
+    }
+    float* out = V + tile * C + c;
+    const long xs = g.T * C;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x2*>(out + (long)(i * 6 + j) * xs) = d[i][j];
+}
+
+__global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restrict__ M, int N, W4Geom g, const float* __restrict__ bias,
+                                                           float* __restrict__ y, int ldy, int accumulate) {
+    const int N2 = N >> 1;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= g.T * N2) return;
+    const long tile = idx / N2;
+    const int c = (int)(idx - tile * N2) * 2;
+    const int per = g.TY * g.TX;
+    const int n = (int)(tile / per);
+    const int rem = (int)(tile - (long)n * per);
+    const int ty = rem / g.TX, tx = rem - ty * g.TX;
+    const float* in = M + tile * N + c;
+    const long xs = g.T * N;
+    f32x2 s[4][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        f32x2 m[6], o[4];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) m[i] = *reinterpret_cast<const f32x2*>(in + (long)(i * 6 + j) * xs);
+        at4(m[0], m[1], m[2], m[3], m[4], m[5], o);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s[i][j] = o[i];
+    }
+    f32x2 bv = {0.f, 0.f};
+    if (bias) bv = *reinterpret_cast<const f32x2*>(bias + c);
+    float* dst = y + (((long)n * g.H + 4 * ty) * g.W + 4 * tx) * ldy + c;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f32x2 o[4];
+        at4(s[i][0], s[i][1], s[i][2], s[i][3], s[i][4], s[i][5], o);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float* p = dst + ((long)i * g.W + j) * ldy;
+            f32x2 v = o[j] + bv;
+            if (accumulate) v += *reinterpret_cast<const f32x2*>(p);
+            *reinterpret_cast<f32x2*>(p) = v;
+        }
+    }
+}
+
+// thread = (k, n) with n fastest (coalesced U stores).  forward: g[r][s] = w[r][s][k][n];  dgrad: g[r][s] = w[2-r][2-s][n][k]
+__global__ __launch_bounds__(256) void wino4_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int cin, int cout, int dgrad) {
+    const int K = dgrad ? cout : cin, N = dgrad ? cin : cout;
+    const long kn = (long)K * N;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= kn) return;
+    const int k = (int)(i / N), n = (int)(i - (long)k * N);
+    float gm[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+            gm[r][s] = dgrad ? w[((long)((2 - r) * 3 + (2 - s)) * cin + n) * cout + k] : w[((long)(r * 3 + s) * cin + k) * cout + n];
+    float t[6][3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const float g0 = gm[0][s], g1 = gm[1][s], g2 = gm[2][s];
+        const float e = (g0 + g2) * (1.f / 6.f), f = g0 * (1.f / 24.f) + g2 * (1.f / 6.f);
+        t[0][s] = 0.25f * g0; t[1][s] = -e - g1 * (1.f / 6.f); t[2][s] = -e + g1 * (1.f / 6.f);
+        t[3][s] = f + g1 * (1.f / 12.f); t[4][s] = f - g1 * (1.f / 12.f); t[5][s] = g2;
+    }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+        const float g0 = t[a][0], g1 = t[a][1], g2 = t[a][2];
+        const float e = (g0 + g2) * (1.f / 6.f), f = g0 * (1.f / 24.f) + g2 * (1.f / 6.f);
+        float* o = U + (long)(a * 6) * kn + i;
+        o[0] = 0.25f * g0; o[kn] = -e - g1 * (1.f / 6.f); o[2 * kn] = -e + g1 * (1.f / 6.f);
+        o[3 * kn] = f + g1 * (1.f / 12.f); o[4 * kn] = f - g1 * (1.f / 12.f); o[5 * kn] = g2;
+    }
+}
+
+// dw[r][s][k][n] = (G^T (sum_splits dU[split][36][k][n]) G)[r][s]
+__device__ __forceinline__ void gt3(const float m0, const float m1, const float m2, const float m3, const float m4, const float m5, float (&r)[3]) {
+    const float p = m1 + m2, q = m3 + m4;
+    r[0] = 0.25f * m0 - p * (1.f / 6.f) + q * (1.f / 24.f);
+    r[1] = (m2 - m1) * (1.f / 6.f) + (m3 - m4) * (1.f / 12.f);
+    r[2] = (q - p) * (1.f / 6.f) + m5;
+}
+__global__ __launch_bounds__(256) void wino4_wgrad_out_kernel(const float* __restrict__ dU, int splits, long kn, float* __restrict__ dw) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= kn) return;
+    float m[36];
+#pragma unroll
+    for (int x = 0; x < 36; ++x) m[x] = 0.f;
+    for (int s = 0; s < splits; ++s) {
+        const float* p = dU + (long)s * 36 * kn + i;
+#pragma unroll
+        for (int x = 0; x < 36; ++x) m[x] += p[(long)x * kn];
+    }
+    float t[3][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        float r[3];
+        gt3(m[j], m[6 + j], m[12 + j], m[18 + j], m[24 + j], m[30 + j], r);
+        t[0][j] = r[0]; t[1][j] = r[1]; t[2][j] = r[2];
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float r[3];
+        gt3(t[a][0], t[a][1], t[a][2], t[a][3], t[a][4], t[a][5], r);
+        dw[(long)(a * 3 + 0) * kn + i] = r[0];
+        dw[(long)(a * 3 + 1) * kn + i] = r[1];
+        dw[(long)(a * 3 + 2) * kn + i] = r[2];
+    }
+}
+
+W4Geom geom(int n_img, int h, int w) {
+    W4Geom g{};
+    g.n_img = n_img; g.H = h; g.W = w; g.TY = h / 4; g.TX = w / 4; g.T = (long)n_img * g.TY * g.TX;
+    return g;
+}
+
+// rows (tiles) per split of the weight-gradient GEMMs: enough splits for ~512 blocks, at least 64 tiles each, 16-aligned
+int wgrad_rows_per_split(long T, int cin, int cout) {
+    const long blocks = (long)cdiv(cin, 128) * cdiv(cout, 128) * 36;
+    long s = cdiv(512, blocks);
+    const long maxs = T / 64 > 0 ? T / 64 : 1;
+    if (s > maxs) s = maxs;
+    if (s < 1) s = 1;
+    return (int)((cdiv(T, s) + 15) / 16 * 16);
+}
+
+}  // namespace
+
+extern "C" int runet_wino4_supported(int h, int w, int k, int n) {
+    return (h >= 4 && w >= 4 && h % 4 == 0 && w % 4 == 0 && k >= 16 && k % 4 == 0 && n >= 4 && n % 4 == 0) ? 1 : 0;
+}
+
+extern "C" long runet_wino4_workspace_floats(int n_img, int h, int w, int k, int n) {
+    return 36L * n_img * (h / 4) * (w / 4) * ((long)k + n);
+}
+
+extern "C" int runet_wino4_weights(const float* w_hwio, float* U, int cin, int cout, int dgrad, void* stream) {
+    RUNET_REQUIRE(w_hwio && U && cin > 0 && cout > 0, "bad arguments");
+    hipLaunchKernelGGL(wino4_weight_kernel, dim3(cdiv((long)cin * cout, 256)), dim3(256), 0, (hipStream_t)stream, w_hwio, U, cin, cout, dgrad);
+    RUNET_CHECK_LAUNCH();
+}
+
+extern "C" int runet_wino4_conv(const float* x, int ldx, const float* U, const float* bias, float* y, int ldy, int n_img, int h, int w, int k, int n,
+                                int accumulate, float* workspace, long workspace_floats, void* stream) {
+    RUNET_REQUIRE(x && U && y && workspace, "null pointer");
+    RUNET_REQUIRE(runet_wino4_supported(h, w, k, n), "shape not supported by the F(4x4,3x3) path (H, W multiples of 4; K, N multiples of 4)");
+    RUNET_REQUIRE(ldx >= k && ldx % 2 == 0 && ldy >= n && ldy % 2 == 0, "pixel strides must be even and cover the channels");
+    RUNET_REQUIRE(((uintptr_t)x % 8) == 0 && ((uintptr_t)y % 8) == 0 && ((uintptr_t)U % 16) == 0 && ((uintptr_t)workspace % 16) == 0 &&
+                  (!bias || ((uintptr_t)bias % 8) == 0), "alignment");
+    RUNET_REQUIRE(workspace_floats >= runet_wino4_workspace_floats(n_img, h, w, k, n), "workspace too small (runet_wino4_workspace_floats)");
+    const W4Geom g = geom(n_img, h, w);
+    hipStream_t st = (hipStream_t)stream;
+    float* V = workspace;
+    float* M = workspace + 36L * g.T * k;
+    hipLaunchKernelGGL(wino4_input_kernel<0>, dim3(cdiv(g.T * (k / 2), 256)), dim3(256), 0, st, x, ldx, k, g, V);
+    const int rc = runet_gemm_batched(V, k, g.T * k, U, (long)k * n, M, n, g.T * n, 36, (int)g.T, k, n, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(wino4_output_kernel, dim3(cdiv(g.T * (n / 2), 256)), dim3(256), 0, st, M, n, g, bias, y, ldy, accumulate);
+    RUNET_CHECK_LAUNCH();
+}
+
+extern "C" long runet_wino4_wgrad_workspace_floats(int n_img, int h, int w, int cin, int cout) {
+    const long T = (long)n_img * (h / 4) * (w / 4);
+    return 36L * T * ((long)cin + cout) + (long)cdiv(T, wgrad_rows_per_split(T, cin, cout)) * 36 * cin * cout;
+}
+
+extern "C" int runet_wino4_wgrad(const float* x, int ldx, const float* dy, int ldy, float* dw, float* workspace, long workspace_floats, int n_img,
+                                 int h, int w, int cin, int cout, void* stream) {
+    RUNET_REQUIRE(x && dy && dw && workspace, "null pointer");
+    RUNET_REQUIRE(runet_wino4_supported(h, w, cin, cout) && cout >= 16, "shape not supported by the F(4x4,3x3) weight gradient");
+    RUNET_REQUIRE(ldx >= cin && ldx % 2 == 0 && ldy >= cout && ldy % 2 == 0, "pixel strides must be even and cover the channels");
+    RUNET_REQUIRE(((uintptr_t)x % 8) == 0 && ((uintptr_t)dy % 8) == 0 && ((uintptr_t)workspace % 16) == 0, "alignment");
+    RUNET_REQUIRE(workspace_floats >= runet_wino4_wgrad_workspace_floats(n_img, h, w, cin, cout), "workspace too small (runet_wino4_wgrad_workspace_floats)");
+    const W4Geom g = geom(n_img, h, w);
+    hipStream_t st = (hipStream_t)stream;
+    float* V = workspace;
+    float* Z = V + 36L * g.T * cin;
+    float* dU = Z + 36L * g.T * cout;
+    const int rps = wgrad_rows_per_split(g.T, cin, cout);
+    const int splits = cdiv(g.T, rps);
+    hipLaunchKernelGGL(wino4_input_kernel<0>, dim3(cdiv(g.T * (cin / 2), 256)), dim3(256), 0, st, x, ldx, cin, g, V);
+    hipLaunchKernelGGL(wino4_input_kernel<1>, dim3(cdiv(g.T * (cout / 2), 256)), dim3(256), 0, st, dy, ldy, cout, g, Z);
+    const int rc = runet_gemm_tn_batched(V, cin, g.T * cin, Z, cout, g.T * cout, dU, 36, (int)g.T, cin, cout, rps, stream);
+    if (rc) return rc;
+    const long kn = (long)cin * cout;
+    hipLaunchKernelGGL(wino4_wgrad_out_kernel, dim3(cdiv(kn, 256)), dim3(256), 0, st, dU, splits, kn, dw);
+    RUNET_CHECK_LAUNCH();
+}

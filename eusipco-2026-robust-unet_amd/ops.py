@@ -103,9 +103,20 @@ def _wino_case(h, w, kh, dil, k, n, cin_w):
     return USE_WINOGRAD and kh == 3 and dil == 1 and cin_w == k and bool(lib.runet_wino_supported(h, w, k, n))
 
 
+USE_WINOGRAD4 = USE_WINOGRAD and os.environ.get("RUNET_NO_WINOGRAD4", "0") != "1"
+
+
+def _wino4_case(h, w, kh, dil, k, n, cin_w):
+    """Deep layers (>= 256 channels on one side, <= 128x128 pixels): unfused F(4x4,3x3) beats the fused F(2x2) kernel (tools/bench_conv.py)."""
+    return (USE_WINOGRAD4 and kh == 3 and dil == 1 and cin_w == k and max(k, n) >= 256 and min(k, n) >= 128 and h * w <= 128 * 128
+            and bool(lib.runet_wino4_supported(h, w, k, n)))
+
+
 def conv_fwd(x, w_hwio, bias=None, out=None, dil=1, accumulate=False):
     n, h, w, cin = x.shape
     kh, kw, cin_w, cout = w_hwio.shape
+    if _wino4_case(h, w, kh, dil, cin, cout, cin_w):
+        return wino4_conv(x, wino4_weights(w_hwio), bias, out=out, accumulate=accumulate)
     if _wino_case(h, w, kh, dil, cin, cout, cin_w):
         return wino_conv(x, wino_weights(w_hwio), bias, out=out, accumulate=accumulate)
     if out is None:
@@ -149,6 +160,8 @@ def conv_dgrad(dy, w_hwio, out=None, dil=1, accumulate=False):
     n, h, w, cout = dy.shape
     kh, kw, cin, cout_w = w_hwio.shape
     assert cout_w == cout
+    if _wino4_case(h, w, kh, dil, cout, cin, cout):
+        return wino4_conv(dy, wino4_weights(w_hwio, dgrad=True), None, out=out, accumulate=accumulate)
     if _wino_case(h, w, kh, dil, cout, cin, cout):
         return wino_conv(dy, wino_weights(w_hwio, dgrad=True), None, out=out, accumulate=accumulate)
     if out is None:
@@ -168,7 +181,11 @@ def conv_wgrad(x, dy, kh, kw, cin_w=None, dil=1, out=None):
     if prof:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    if USE_WINOGRAD and kh == 3 and dil == 1 and cin_w == cin and h % 2 == 0 and w % 2 == 0 and cin >= 16:
+    if _wino4_case(h, w, kh, dil, cin, cout, cin_w) and cout >= 16:
+        name = "wino4 wgrad (input x2 + gemm + output)"
+        ws = _workspace4(lib.runet_wino4_wgrad_workspace_floats(n, h, w, cin, cout), x.device)
+        check(lib.runet_wino4_wgrad(x.data_ptr(), ld(x), dy.data_ptr(), ld(dy), out.data_ptr(), ws.data_ptr(), ws.numel(), n, h, w, cin, cout, stream()))
+    elif USE_WINOGRAD and kh == 3 and dil == 1 and cin_w == cin and h % 2 == 0 and w % 2 == 0 and cin >= 16:
         name = "wino_wgrad_kernel(+reduce)"
         nws = lib.runet_wino_wgrad_workspace_floats(n, h, w, cin, cout)
         ws = workspace(nws, x.device)
@@ -325,4 +342,56 @@ def convt4_wgrad(x, dy, out=None):
     ws = workspace(lib.runet_conv_wgrad_general_workspace_floats(n * h * w, cin, cout, 4, 4), x.device)
     check(lib.runet_conv_wgrad_general(x.data_ptr(), ld(x), dy.data_ptr(), ld(dy), out.data_ptr(), ws.data_ptr(), ws.numel(), n, h, w, cin, cin,
                                        cout, 4, 4, 2, 1, 1, 1, stream()))
+    return out
+
+
+# ------------------------------------------------------------------------------- Winograd F(4x4,3x3), unfused (deep layers)
+_ws4 = {}
+
+
+def _workspace4(nfloats, device):
+    buf = _ws4.get(device.index)
+    if buf is None or buf.numel() < nfloats:
+        buf = torch.empty(int(nfloats), device=device, dtype=torch.float32)
+        _ws4[device.index] = buf
+    return buf
+
+
+def wino4_ok(h, w, k, n):
+    return bool(lib.runet_wino4_supported(h, w, k, n))
+
+
+def wino4_weights(w_hwio, dgrad=False):
+    """HWIO 3x3 weight -> U[36][K][N] (forward: K=cin, N=cout; dgrad: rotated filter, K=cout, N=cin)."""
+    _, _, cin, cout = w_hwio.shape
+    k, n = (cout, cin) if dgrad else (cin, cout)
+    U = torch.empty((36, k, n), device=w_hwio.device, dtype=torch.float32)
+    check(lib.runet_wino4_weights(w_hwio.data_ptr(), U.data_ptr(), cin, cout, int(dgrad), stream()))
+    return U
+
+
+def wino4_conv(x, U, bias=None, out=None, accumulate=False):
+    n, h, w, k = x.shape
+    nn_ = U.shape[2]
+    if out is None:
+        out = empty_nhwc(n, h, w, nn_, x)
+    ws = _workspace4(lib.runet_wino4_workspace_floats(n, h, w, k, nn_), x.device)
+    if _PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(lib.runet_wino4_conv(x.data_ptr(), ld(x), U.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(), ld(out),
+                               n, h, w, k, nn_, int(accumulate), ws.data_ptr(), ws.numel(), stream()))
+    if _PROFILE is not None:
+        e1.record()
+        _PROFILE.append(("wino4 (input+gemm+output)", 2.0 * n * h * w * 9 * k * nn_, e0, e1))
+    return out
+
+
+def wino4_wgrad(x, dy, out=None):
+    n, h, w, cin = x.shape
+    cout = dy.shape[3]
+    if out is None:
+        out = torch.empty((3, 3, cin, cout), device=x.device, dtype=torch.float32)
+    ws = _workspace4(lib.runet_wino4_wgrad_workspace_floats(n, h, w, cin, cout), x.device)
+    check(lib.runet_wino4_wgrad(x.data_ptr(), ld(x), dy.data_ptr(), ld(dy), out.data_ptr(), ws.data_ptr(), ws.numel(), n, h, w, cin, cout, stream()))
     return out

@@ -165,6 +165,26 @@ int runet_adam_multi(const long long* table, int n_tensors, const int* chunks, i
 /* ---- ModelEvaluator.calculate_metrics counts (Main_Final.py:519-547): counts[n] = {tp, pred>thr, target!=0, agree} ---- */
 int runet_seg_counts(const float* pred, const float* target, long long* counts, int n_img, long per_img, float threshold, void* stream);
 
+/* ---- batched plain GEMMs (fp32 MFMA, LDS-tiled; the position-GEMMs of the F(4x4,3x3) path) ----
+ * runet_gemm_batched:    C[z][rows][n] = A[z][rows][k] . B[z][k][n]   (row strides lda / n / ldc, batch strides in floats)
+ * runet_gemm_tn_batched: C[split][z][k][n] = sum over rows of split of A[z][row][k] * B[z][row][n];  splits = ceil(rows / rows_per_split) */
+int runet_gemm_batched(const float* a, int lda, long stride_a, const float* b, long stride_b, float* c, int ldc, long stride_c, int batch, int rows,
+                       int k, int n, void* stream);
+int runet_gemm_tn_batched(const float* a, int lda, long stride_a, const float* b, int ldb, long stride_b, float* c, int batch, int rows, int k, int n,
+                          int rows_per_split, void* stream);
+
+/* ---- Winograd F(4x4,3x3), unfused, for the deep 3x3 convolutions (Main_Final.py:157,159 at >= 256 channels) and their autograd ----
+ * U [36][K][N] from runet_wino4_weights (dgrad != 0: rotated filter, K = cout, N = cin).  conv: x [n,h,w,K] -> y [n,h,w,N] ('same'), H, W % 4 == 0.
+ * workspace: runet_wino4_workspace_floats / runet_wino4_wgrad_workspace_floats floats, 16-byte aligned. */
+int runet_wino4_supported(int h, int w, int k, int n);
+long runet_wino4_workspace_floats(int n_img, int h, int w, int k, int n);
+int runet_wino4_weights(const float* w_hwio, float* U, int cin, int cout, int dgrad, void* stream);
+int runet_wino4_conv(const float* x, int ldx, const float* U, const float* bias, float* y, int ldy, int n_img, int h, int w, int k, int n,
+                     int accumulate, float* workspace, long workspace_floats, void* stream);
+long runet_wino4_wgrad_workspace_floats(int n_img, int h, int w, int cin, int cout);
+int runet_wino4_wgrad(const float* x, int ldx, const float* dy, int ldy, float* dw, float* workspace, long workspace_floats, int n_img, int h, int w,
+                      int cin, int cout, void* stream);
+
 /* ---- DeepLabV3+ baseline (Main_Final.py:325-433): the same implicit-GEMM kernels with general geometry ----
  * runet_conv2d_general: Conv2d(kh x kw <= 7x7, stride 1|2, padding, dilation).  mode RUNET_CONV_FWD: x [n,hin,win,cin] -> y [n,ho,wo,cout],
  * w [kh,kw,cin_w,cout];  mode RUNET_CONV_DGRAD: x := dy [n,ho,wo,cin(=conv Cout)] -> y := dx [n,hin,win,cout(=conv Cin)], w [kh,kw,cout,cin].

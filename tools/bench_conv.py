@@ -45,6 +45,13 @@ for cin, cout, div, k, dil in LAYERS:
         twf = timeit(lambda: ops.wino_conv(x, U)); twd = timeit(lambda: ops.wino_conv(dy, Ud))
         tot["wino_fwd"] = tot.get("wino_fwd", 0.0) + twf; tot["wino_dgrad"] = tot.get("wino_dgrad", 0.0) + twd
         wino = f" | wino fwd {twf:7.3f} ms {flop/twf/1e9:6.1f} TF dgrad {twd:7.3f} ms {flop/twd/1e9:6.1f} TF"
+    if k == 3 and dil == 1 and ops.wino4_ok(h, h, cin, cout) and cin >= 128:
+        U4 = ops.wino4_weights(w); U4d = ops.wino4_weights(w, dgrad=True)
+        t4f = timeit(lambda: ops.wino4_conv(x, U4)); t4d = timeit(lambda: ops.wino4_conv(dy, U4d)); t4w = timeit(lambda: ops.wino4_wgrad(x, dy))
+        t4u = timeit(lambda: ops.wino4_weights(w))
+        for kk, vv in (("w4_fwd", t4f), ("w4_dgrad", t4d), ("w4_wgrad", t4w), ("w4_weights", t4u)):
+            tot[kk] = tot.get(kk, 0.0) + vv
+        wino += f" | F4 fwd {t4f:6.3f} dgrad {t4d:6.3f} wgrad {t4w:6.3f} U {t4u:6.3f} ms"
     print(f"{cin:5d}->{cout:5d} @{h:4d} k{k} d{dil}: fwd {tf:7.3f} ms {flop/tf/1e9:6.1f} TF | dgrad {td:7.3f} ms {flop/td/1e9:6.1f} TF"
           f" | wgrad {tw:7.3f} ms {flop/tw/1e9:6.1f} TF" + wino, flush=True)
 print("sum ms:", tot)
