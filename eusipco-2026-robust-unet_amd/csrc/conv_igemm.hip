@@ -20,6 +20,7 @@
 //   GEMM M = cin, N = cout, K = pixels (step 16 pixels); split over pixel ranges (grid.z) into
 //   partial slabs that a second kernel sums in a fixed order (bitwise reproducible, no atomics).
 #include "runet_common.h"
+#include <stdlib.h>
 #include "../../include/runet_hip.h"
 
 namespace {
@@ -1037,6 +1038,11 @@ extern "C" int runet_gemm_batched(const float* a, int lda, long stride_a, const 
     g.w_sk = n; g.w_sn = 1; g.Nimg = 1; g.H = 1; g.W = rows; g.Hin = 1; g.Win = rows; g.a_scale = 1; g.KH = 1; g.KW = 1;
     g.Hout = 1; g.Wout = rows; g.o_scale = 1; g.zbatch = 1; g.zs_x = stride_a; g.zs_w = stride_b; g.zs_y = stride_c;
     hipStream_t st = (hipStream_t)stream;
+    static const bool old_path = getenv("RUNET_GEMM_OLD") != nullptr;      // A/B switch for tools/bench_gemm.py
+    if (!old_path && n >= 96) {
+        runet_gemm_nn_launch(a, lda, stride_a, b, stride_b, c, ldc, stride_c, batch, rows, k, n, st);
+        RUNET_CHECK_LAUNCH();
+    }
     const long b128 = (long)cdiv(rows, 128) * cdiv(n, 128) * batch;
     if (n % 128 == 0 && b128 >= 256) launch_igemm<128, 128, 64, 64, false>(g, batch, st);
     else if (n > 32 && (long)cdiv(rows, 128) * cdiv(n, 64) * batch >= 256) launch_igemm<128, 64, 64, 32, false>(g, batch, st);
@@ -1059,6 +1065,11 @@ extern "C" int runet_gemm_tn_batched(const float* a, int lda, long stride_a, con
     g.pix_per_split = rows_per_split;
     hipStream_t st = (hipStream_t)stream;
     const bool big = k > 64 && n > 64;
+    static const bool old_path = getenv("RUNET_GEMM_OLD") != nullptr;
+    if (!old_path && big) {
+        runet_gemm_tn_launch(a, lda, stride_a, b, ldb, stride_b, c, batch, rows, k, n, rows_per_split, st);
+        RUNET_CHECK_LAUNCH();
+    }
     const int tiles = big ? cdiv(k, 128) * cdiv(n, 128) : cdiv(k, 64) * cdiv(n, 64);
     dim3 grid(tiles, batch, splits);
     if (big) hipLaunchKernelGGL((wgrad_kernel<128, 128, 64, 64>), grid, dim3(256), 2 * (16 * (128 + 4) * 2) * sizeof(float), st, g);

@@ -1,0 +1,278 @@
+// Batched fp32 GEMMs on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32), the position-GEMMs of the unfused Winograd F(4x4,3x3)
+// path (conv_winograd4.hip):
+//   gemm_nn_kernel: C[z][rows][n]      = A[z][rows][k] . B[z][k][n]
+//   gemm_tn_kernel: C[split][z][k][n]  = sum over the split's rows of A[z][row][k] * B[z][row][n]
+// Block = 128 x 128 output tile, 4 waves of 64 x 64 (2 x 2 MFMA tiles, 64 accumulator registers... x4 = 128 per lane), 16-deep
+// k-steps through a THREE-stage LDS ring: the global loads of step s+2 are in flight while step s multiplies, and the first
+// operand fragments of step s+1 are read from LDS during the second half of step s, so the barrier at the end of a step does not
+// expose LDS latency (the two-stage form of conv_igemm.hip reads all fragments right after the barrier).  Every global load is
+// unconditional (clamped address, value zeroed by a select) so the compiler's vmcnt counting stays exact.
+#include "runet_common.h"
+#include "../../include/runet_hip.h"
+#include <stdlib.h>
+
+namespace {
+
+struct GemmArgs {
+    const float* a; int lda; long sa;
+    const float* b; int ldb; long sb;
+    float* c; int ldc; long sc;
+    int rows, k, n;
+    int rps;            // TN: rows per split (multiple of 16)
+};
+
+constexpr int BK = 16;
+constexpr int NN_LDA = BK + 4, NN_LDB = 128 + 4;
+constexpr int NN_A = 128 * NN_LDA, NN_B = BK * NN_LDB, NN_STAGE = NN_A + NN_B;
+
+__global__ __launch_bounds__(256, 2) void gemm_nn_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm0 = (wid >> 1) * 64, wn0 = (wid & 1) * 64;
+    const int li = lane & 31, lh = lane >> 5;
+    const int m0 = blockIdx.x * 128, n0 = blockIdx.y * 128;
+    const float* A = g.a + (long)blockIdx.z * g.sa;
+    const float* B = g.b + (long)blockIdx.z * g.sb;
+    float* C = g.c + (long)blockIdx.z * g.sc;
+
+    // ---- loaders: A item (row, k-quad) = (tid >> 2 (+64), tid & 3);  B item (k-row, n-quad) = (tid >> 5 (+8), tid & 31)
+    const int akq = tid & 3, bnq = tid & 31;
+    long aoff[2]; bool aok[2];
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+        const int r = m0 + (tid >> 2) + 64 * v;
+        aok[v] = r < g.rows;
+        aoff[v] = (long)(aok[v] ? r : 0) * g.lda + akq * 4;
+    }
+    const bool bn_ok = n0 + bnq * 4 < g.n;
+    const int bcol = bn_ok ? n0 + bnq * 4 : 0;
+    f32x4 ra[2], rb[2];
+    bool oka[2], okb[2];              // validity of the tile held in ra/rb (applied at the LDS store, so the loads stay in flight)
+    auto load_tile = [&](int kofs) {
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            oka[v] = aok[v] && kofs + akq * 4 < g.k;
+            ra[v] = *reinterpret_cast<const f32x4*>(A + (oka[v] ? aoff[v] + kofs : 0));
+        }
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const int kr = kofs + (tid >> 5) + 8 * v;
+            okb[v] = bn_ok && kr < g.k;
+            rb[v] = *reinterpret_cast<const f32x4*>(B + (okb[v] ? (long)kr * g.ldb + bcol : 0));
+        }
+    };
+    auto store_tile = [&](int buf) {
+        float* As = smem + buf * NN_STAGE;
+        float* Bs = As + NN_A;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int v = 0; v < 2; ++v) *reinterpret_cast<f32x4*>(As + ((tid >> 2) + 64 * v) * NN_LDA + akq * 4) = oka[v] ? ra[v] : zero;
+#pragma unroll
+        for (int v = 0; v < 2; ++v) *reinterpret_cast<f32x4*>(Bs + ((tid >> 5) + 8 * v) * NN_LDB + bnq * 4) = okb[v] ? rb[v] : zero;
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    struct Frag { f32x4 a[2]; float b[2][4]; };
+    auto read_frag = [&](int buf, int kh, Frag& f) {
+        const float* As = smem + buf * NN_STAGE;
+        const float* Bs = As + NN_A;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) f.a[a] = *reinterpret_cast<const f32x4*>(As + (wm0 + a * 32 + li) * NN_LDA + kh * 8 + 4 * lh);
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) f.b[b][q] = Bs[(kh * 8 + 4 * lh + q) * NN_LDB + wn0 + b * 32 + li];
+    };
+    auto mma = [&](const Frag& f) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[a][q], f.b[b][q], acc[a][b], 0, 0, 0);
+    };
+
+    const int nks = (g.k + BK - 1) / BK;
+    // prologue: tiles 0 and 1 into stages 0 and 1 (a k extent of one step loads an all-zero second tile: kofs >= k)
+    load_tile(0);
+    store_tile(0);
+    load_tile(BK);
+    store_tile(1);
+    __syncthreads();
+    Frag f0, f1;
+    read_frag(0, 0, f0);
+    __builtin_amdgcn_s_waitcnt(0xc07f);     // lgkmcnt(0): the loop header then merges two states with nothing outstanding
+    int cur = 0;                      // stage holding tile s
+    // The body is branch-free: past the end it re-loads zeros (kofs >= k), stores them into a stage nobody reads again and
+    // prefetches fragments that are never multiplied, which keeps the compiler's waitcnt bookkeeping exact.
+    for (int s = 0; s < nks; ++s) {
+        const int nxt = cur == 2 ? 0 : cur + 1, nx2 = nxt == 2 ? 0 : nxt + 1;
+        load_tile((s + 2) * BK);
+        read_frag(cur, 1, f1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(f0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_frag(nxt, 0, f0);                      // tile s+1 became visible at the barrier that ended step s-1
+        __builtin_amdgcn_sched_barrier(0);
+        mma(f1);
+        __builtin_amdgcn_sched_barrier(0);
+        store_tile(nx2);                            // stage of tile s-1: its last reads finished before the previous barrier
+        __syncthreads();
+        cur = nxt;
+    }
+
+    // ---- epilogue: lane holds column li of each 32-wide tile, rows (r&3) + 8*(r>>2) + 4*lh
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (row < g.rows) {
+                float* crow = C + (long)row * g.ldc;
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const int col = n0 + wn0 + b * 32 + li;
+                    if (col < g.n) crow[col] = acc[a][b][r];
+                }
+            }
+        }
+}
+
+// ---- TN: contraction over rows.  LDS stage = As[16 rows][128 k] + Bs[16 rows][128 n]; operands are scalar LDS reads (row = t, column = lane)
+constexpr int TN_LD = 128 + 4;
+constexpr int TN_STAGE = 2 * BK * TN_LD;
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm0 = (wid >> 1) * 64, wn0 = (wid & 1) * 64;
+    const int li = lane & 31, lh = lane >> 5;
+    const int n_tiles = (g.n + 127) >> 7;
+    const int k0 = (blockIdx.x / n_tiles) * 128, n0 = (blockIdx.x % n_tiles) * 128;
+    const int z = blockIdx.y;
+    const float* A = g.a + (long)z * g.sa;
+    const float* B = g.b + (long)z * g.sb;
+    const int t_begin = blockIdx.z * g.rps;
+    const int t_end = min(g.rows, t_begin + g.rps);
+
+    // loaders: item (t-row, quad) = (tid >> 5 (+8), tid & 31) for both operands
+    const int q4 = (tid & 31) * 4;
+    const bool ak_ok = k0 + q4 < g.k, bn_ok = n0 + q4 < g.n;
+    const int acol = ak_ok ? k0 + q4 : 0, bcol = bn_ok ? n0 + q4 : 0;
+    f32x4 ra[2], rb[2];
+    bool okt[2];
+    auto load_tile = [&](int t0) {
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const int t = t0 + (tid >> 5) + 8 * v;
+            okt[v] = t < t_end;
+            const long tr = okt[v] ? t : 0;
+            ra[v] = *reinterpret_cast<const f32x4*>(A + tr * g.lda + acol);
+            rb[v] = *reinterpret_cast<const f32x4*>(B + tr * g.ldb + bcol);
+        }
+    };
+    auto store_tile = [&](int buf) {
+        float* As = smem + buf * TN_STAGE;
+        float* Bs = As + BK * TN_LD;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            *reinterpret_cast<f32x4*>(As + ((tid >> 5) + 8 * v) * TN_LD + q4) = (okt[v] && ak_ok) ? ra[v] : zero;
+            *reinterpret_cast<f32x4*>(Bs + ((tid >> 5) + 8 * v) * TN_LD + q4) = (okt[v] && bn_ok) ? rb[v] : zero;
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    struct Frag { float a[4][2], b[4][2]; };          // four k2-steps (8 rows of the stage)
+    auto read_frag = [&](int buf, int half, Frag& f) {
+        const float* As = smem + buf * TN_STAGE;
+        const float* Bs = As + BK * TN_LD;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int row = half * 8 + 2 * s + lh;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) f.a[s][a] = As[row * TN_LD + wm0 + a * 32 + li];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) f.b[s][b] = Bs[row * TN_LD + wn0 + b * 32 + li];
+        }
+    };
+    auto mma = [&](const Frag& f) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[s][a], f.b[s][b], acc[a][b], 0, 0, 0);
+    };
+
+    const int nks = (t_end - t_begin + BK - 1) / BK;
+    load_tile(t_begin);
+    store_tile(0);
+    load_tile(t_begin + BK);
+    store_tile(1);
+    __syncthreads();
+    Frag f0, f1;
+    read_frag(0, 0, f0);
+    __builtin_amdgcn_s_waitcnt(0xc07f);     // lgkmcnt(0), see gemm_nn_kernel
+    int cur = 0;
+    for (int s = 0; s < nks; ++s) {          // branch-free body, see gemm_nn_kernel
+        const int nxt = cur == 2 ? 0 : cur + 1, nx2 = nxt == 2 ? 0 : nxt + 1;
+        load_tile(t_begin + (s + 2) * BK);
+        read_frag(cur, 1, f1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(f0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_frag(nxt, 0, f0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(f1);
+        __builtin_amdgcn_sched_barrier(0);
+        store_tile(nx2);
+        __syncthreads();
+        cur = nxt;
+    }
+
+    float* C = g.c + ((long)blockIdx.z * gridDim.y + z) * g.k * g.n;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int col = n0 + wn0 + b * 32 + li;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kk = k0 + wm0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (col < g.n && kk < g.k) C[(long)kk * g.n + col] = acc[a][b][r];
+            }
+    }
+}
+
+}  // namespace
+
+int runet_gemm_nn_launch(const float* a, int lda, long sa, const float* b, long sb, float* c, int ldc, long sc, int batch, int rows, int k, int n,
+                         hipStream_t st) {
+    GemmArgs g{};
+    g.a = a; g.lda = lda; g.sa = sa; g.b = b; g.ldb = n; g.sb = sb; g.c = c; g.ldc = ldc; g.sc = sc; g.rows = rows; g.k = k; g.n = n;
+    hipLaunchKernelGGL(gemm_nn_kernel, dim3(cdiv(rows, 128), cdiv(n, 128), batch), dim3(256), 3 * NN_STAGE * sizeof(float), st, g);
+    return 0;
+}
+
+int runet_gemm_tn_launch(const float* a, int lda, long sa, const float* b, int ldb, long sb, float* c, int batch, int rows, int k, int n, int rps,
+                         hipStream_t st) {
+    GemmArgs g{};
+    g.a = a; g.lda = lda; g.sa = sa; g.b = b; g.ldb = ldb; g.sb = sb; g.c = c; g.rows = rows; g.k = k; g.n = n; g.rps = rps;
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(cdiv(k, 128) * cdiv(n, 128), batch, cdiv(rows, rps)), dim3(256), 3 * TN_STAGE * sizeof(float), st, g);
+    return 0;
+}

@@ -37,6 +37,12 @@ extern "C" void runet_set_error(const char* msg);
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// gemm.hip (internal launchers behind runet_gemm_batched / runet_gemm_tn_batched)
+int runet_gemm_nn_launch(const float* a, int lda, long sa, const float* b, long sb, float* c, int ldc, long sc, int batch, int rows, int k, int n,
+                         hipStream_t st);
+int runet_gemm_tn_launch(const float* a, int lda, long sa, const float* b, int ldb, long sb, float* c, int batch, int rows, int k, int n, int rps,
+                         hipStream_t st);
+
 // ---- wave / block reductions (wave = 64 lanes) ----
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
