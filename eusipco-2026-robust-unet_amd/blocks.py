@@ -184,13 +184,14 @@ def rb_forward(x, p: RBParams, training, mask=None, save=True, stats_hook=None):
         ss, hs, mean_s, invstd_s, _ = bn_coeff(r, p.bns, training, sm, stats_hook=stats_hook)
     else:
         r, ss, hs, mean_s, invstd_s = x, None, None, None, None
-    t1 = ops.conv_fwd(x, p.w1)
+    kv1, kv2 = ({}, {}) if save else (None, None)      # F(4x4) layers: the transformed inputs are kept for the weight gradients
+    t1 = ops.conv_fwd(x, p.w1, keep_v=kv1)
     s1, h1, mean1, invstd1, _ = bn_coeff(t1, p.bn1, training, sm, stats_hook=stats_hook)
     use_mask = mask if training else None
     a1 = bn_apply(t1, s1, h1, use_mask, relu=True)
     if not save:
         del t1
-    t2 = ops.conv_fwd(a1, p.w2)
+    t2 = ops.conv_fwd(a1, p.w2, keep_v=kv2)
     s2, h2, mean2, invstd2, nc = bn_coeff(t2, p.bn2, training, sm, want_minmax=True, stats_hook=stats_hook)
     mean_nc, _, max_nc, min_nc, imax, imin = nc
     A, B, ca, avg, mx, tval = (sm.f(n * c) for _ in range(6))
@@ -211,7 +212,7 @@ def rb_forward(x, p: RBParams, training, mask=None, save=True, stats_hook=None):
         return out, None
     ctx = dict(x=x, r=r, t1=t1, a1=a1, t2=t2, out=out, mask=use_mask, p=p, sync=stats_hook if training else None, s1=s1, mean1=mean1, invstd1=invstd1, s2=s2, h2=h2,
                mean2=mean2, invstd2=invstd2, ss=ss, mean_s=mean_s, invstd_s=invstd_s, A=A, B=B, ca=ca, avg=avg, mx=mx, idx=idx,
-               tval=tval, mean_nc=mean_nc, smap=smap, amax=amax, sa=sa)
+               tval=tval, mean_nc=mean_nc, smap=smap, amax=amax, sa=sa, v1=kv1.get("V"), v2=kv2.get("V"))
     return out, ctx
 
 
@@ -253,12 +254,14 @@ def rb_backward(ctx, dout, sink, pre="", need_dx=True):
     check(lib.runet_rb_bwd3(dv.data_ptr(), ops.ld(dv), t2.data_ptr(), ops.ld(t2), sa.data_ptr(), dsm.data_ptr(), amax.data_ptr(),
                             ctx["ca"].data_ptr(), davg.data_ptr(), dmx.data_ptr(), ctx["idx"].data_ptr(), ctx["mean2"].data_ptr(),
                             ctx["invstd2"].data_ptr(), ctx["s2"].data_ptr(), use2.data_ptr(), dt2.data_ptr(), ops.ld(dt2), P, hw, c, m_total, st))
-    ops.conv_wgrad(a1, dt2, 3, 3, out=sink.buf(pre, [("conv2.weight", (3, 3, c, c))]))
+    ops.conv_wgrad(a1, dt2, 3, 3, out=sink.buf(pre, [("conv2.weight", (3, 3, c, c))]), v=ctx.get("v2"))
+    ctx["v2"] = None
     da1 = ops.conv_dgrad(dt2, p.w2)
     del dt2
     sums1 = sink.buf(pre, [("bn1.weight", (c,)), ("bn1.bias", (c,))])
     dt1 = bn_backward(da1, t1, ctx["mean1"], ctx["invstd1"], ctx["s1"], sums1, act=a1, mask=ctx["mask"], out=da1, sync=sync)
-    ops.conv_wgrad(x, dt1, 3, 3, cin_w=p.cin_w, out=sink.buf(pre, [("conv1.weight", (3, 3, p.cin_w, c))]))
+    ops.conv_wgrad(x, dt1, 3, 3, cin_w=p.cin_w, out=sink.buf(pre, [("conv1.weight", (3, 3, p.cin_w, c))]), v=ctx.get("v1"))
+    ctx["v1"] = None
     dx = None
     if p.ws is not None:
         sums_s = sink.buf(pre, [("shortcut.1.weight", (c,)), ("shortcut.1.bias", (c,))])

@@ -149,9 +149,13 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel(WinoArgs g) {
             else slot[b] = up[uoff[b]];
         }
     };
-    auto mma_step = [&](int t, const f32x4 (&slot)[2]) {
+    // the A fragment (one ds_read_b128) of step t+1 is read in front of step t's MFMAs: only the first read after the barrier is exposed
+    auto read_a = [&](int t) {
         const int xl = t >> 1, kh = t & 1;
-        const f32x4 a = *reinterpret_cast<const f32x4*>(&V[((wid * 4 + xl) * WT + li) * VLD + kh * 8 + 4 * lh]);
+        return *reinterpret_cast<const f32x4*>(&V[((wid * 4 + xl) * WT + li) * VLD + kh * 8 + 4 * lh]);
+    };
+    auto mma_step = [&](int t, const f32x4 a, const f32x4 (&slot)[2]) {
+        const int xl = t >> 1;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -172,13 +176,16 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel(WinoArgs g) {
         __syncthreads();
         // the sched_barriers pin each load group in FRONT of the MFMAs it overlaps (the scheduler otherwise sinks loads to the
         // end of the region, right in front of their first use)
+        f32x4 afrag[2];
+        afrag[0] = read_a(0);
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             if (t + 3 < 8) load_step(t + 3, c0, ring[(t + 3) & 3]);
             else load_step(t + 3 - 8, cn, ring[(t + 3) & 3]);          // first steps of the NEXT chunk, in flight across the barriers
             if (t == 1) load_halo(cn);                                 // next chunk's halo: in flight during the rest of the MFMAs
+            if (t + 1 < 8) afrag[(t + 1) & 1] = read_a(t + 1);
             __builtin_amdgcn_sched_barrier(0);
-            mma_step(t, ring[t & 3]);
+            mma_step(t, afrag[t & 1], ring[t & 3]);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -400,17 +407,29 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(WinoWgradArgs g) {
         transform_store();
         if (tb + GT < t_end) prefetch(tb + GT);     // issued before the barrier: in flight during barrier + MFMAs
         __syncthreads();
-#pragma unroll
-        for (int xl = 0; xl < 4; ++xl) {
+        // operands of position xl+1 (12 LDS reads) are fetched in front of position xl's 8 MFMAs; without this every MFMA pair waits
+        // for the ds_read issued right before it
+        float fa[2][GT / 2], fb[2][GT / 2][2];
+        auto read_ops = [&](int xl, float (&a)[GT / 2], float (&b)[GT / 2][2]) {
             const int xi = wid * 4 + xl;
 #pragma unroll
             for (int s = 0; s < GT / 2; ++s) {
-                const float a = Vs[(xi * GT + 2 * s + lh) * GCI + li];
-                const float b0 = Zs[(xi * GT + 2 * s + lh) * GCO + li];
-                const float b1 = Zs[(xi * GT + 2 * s + lh) * GCO + 32 + li];
-                acc[xl][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[xl][0], 0, 0, 0);
-                acc[xl][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[xl][1], 0, 0, 0);
+                a[s] = Vs[(xi * GT + 2 * s + lh) * GCI + li];
+                b[s][0] = Zs[(xi * GT + 2 * s + lh) * GCO + li];
+                b[s][1] = Zs[(xi * GT + 2 * s + lh) * GCO + 32 + li];
             }
+        };
+        read_ops(0, fa[0], fb[0]);
+#pragma unroll
+        for (int xl = 0; xl < 4; ++xl) {
+            if (xl + 1 < 4) read_ops(xl + 1, fa[(xl + 1) & 1], fb[(xl + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < GT / 2; ++s) {
+                acc[xl][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[xl & 1][s], fb[xl & 1][s][0], acc[xl][0], 0, 0, 0);
+                acc[xl][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[xl & 1][s], fb[xl & 1][s][1], acc[xl][1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 

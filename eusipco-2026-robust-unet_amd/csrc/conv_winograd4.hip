@@ -228,6 +228,36 @@ extern "C" int runet_wino4_weights(const float* w_hwio, float* U, int cin, int c
     RUNET_CHECK_LAUNCH();
 }
 
+// The three stages of runet_wino4_conv / runet_wino4_wgrad as separate entry points (profiling, reuse of V between forward and
+// weight gradient).  mode 0: V[36][T][c] = B^T d B of the 6x6 patches of src;  mode 1: Z[36][T][c] = A dY A^T of the 4x4 tiles.
+extern "C" int runet_wino4_input(const float* src, int ld, int c, int n_img, int h, int w, int mode, float* V, void* stream) {
+    RUNET_REQUIRE(src && V && runet_wino4_supported(h, w, 16, 4) && c > 0 && c % 2 == 0 && ld >= c && ld % 2 == 0, "bad arguments");
+    RUNET_REQUIRE(((uintptr_t)src % 8) == 0 && ((uintptr_t)V % 8) == 0 && (mode == 0 || mode == 1), "alignment / mode");
+    const W4Geom g = geom(n_img, h, w);
+    if (mode == 0) hipLaunchKernelGGL(wino4_input_kernel<0>, dim3(cdiv(g.T * (c / 2), 256)), dim3(256), 0, (hipStream_t)stream, src, ld, c, g, V);
+    else hipLaunchKernelGGL(wino4_input_kernel<1>, dim3(cdiv(g.T * (c / 2), 256)), dim3(256), 0, (hipStream_t)stream, src, ld, c, g, V);
+    RUNET_CHECK_LAUNCH();
+}
+
+extern "C" int runet_wino4_output(const float* M, int n, int n_img, int h, int w, const float* bias, float* y, int ldy, int accumulate, void* stream) {
+    RUNET_REQUIRE(M && y && runet_wino4_supported(h, w, 16, 4) && n > 0 && n % 2 == 0 && ldy >= n && ldy % 2 == 0, "bad arguments");
+    RUNET_REQUIRE(((uintptr_t)M % 8) == 0 && ((uintptr_t)y % 8) == 0 && (!bias || ((uintptr_t)bias % 8) == 0), "alignment");
+    const W4Geom g = geom(n_img, h, w);
+    hipLaunchKernelGGL(wino4_output_kernel, dim3(cdiv(g.T * (n / 2), 256)), dim3(256), 0, (hipStream_t)stream, M, n, g, bias, y, ldy, accumulate);
+    RUNET_CHECK_LAUNCH();
+}
+
+extern "C" int runet_wino4_wgrad_output(const float* dU, int splits, int cin, int cout, float* dw, void* stream) {
+    RUNET_REQUIRE(dU && dw && splits >= 1 && cin > 0 && cout > 0, "bad arguments");
+    const long kn = (long)cin * cout;
+    hipLaunchKernelGGL(wino4_wgrad_out_kernel, dim3(cdiv(kn, 256)), dim3(256), 0, (hipStream_t)stream, dU, splits, kn, dw);
+    RUNET_CHECK_LAUNCH();
+}
+
+extern "C" int runet_wino4_wgrad_rows_per_split(int n_img, int h, int w, int cin, int cout) {
+    return wgrad_rows_per_split((long)n_img * (h / 4) * (w / 4), cin, cout);
+}
+
 extern "C" int runet_wino4_conv(const float* x, int ldx, const float* U, const float* bias, float* y, int ldy, int n_img, int h, int w, int k, int n,
                                 int accumulate, float* workspace, long workspace_floats, void* stream) {
     RUNET_REQUIRE(x && U && y && workspace, "null pointer");

@@ -112,11 +112,11 @@ def _wino4_case(h, w, kh, dil, k, n, cin_w):
             and bool(lib.runet_wino4_supported(h, w, k, n)))
 
 
-def conv_fwd(x, w_hwio, bias=None, out=None, dil=1, accumulate=False):
+def conv_fwd(x, w_hwio, bias=None, out=None, dil=1, accumulate=False, keep_v=None):
     n, h, w, cin = x.shape
     kh, kw, cin_w, cout = w_hwio.shape
     if _wino4_case(h, w, kh, dil, cin, cout, cin_w):
-        return wino4_conv(x, wino4_weights(w_hwio), bias, out=out, accumulate=accumulate)
+        return wino4_conv(x, wino4_weights(w_hwio), bias, out=out, accumulate=accumulate, keep_v=keep_v)
     if _wino_case(h, w, kh, dil, cin, cout, cin_w):
         return wino_conv(x, wino_weights(w_hwio), bias, out=out, accumulate=accumulate)
     if out is None:
@@ -171,21 +171,19 @@ def conv_dgrad(dy, w_hwio, out=None, dil=1, accumulate=False):
     return out
 
 
-def conv_wgrad(x, dy, kh, kw, cin_w=None, dil=1, out=None):
+def conv_wgrad(x, dy, kh, kw, cin_w=None, dil=1, out=None, v=None):
     n, h, w, cin = x.shape
     cout = dy.shape[3]
     cin_w = cin if cin_w is None else cin_w
     if out is None:
         out = torch.empty((kh, kw, cin_w, cout), device=x.device, dtype=torch.float32)
+    if _wino4_case(h, w, kh, dil, cin, cout, cin_w) and cout >= 16:
+        return wino4_wgrad(x, dy, out=out, v=v)
     prof = _PROFILE is not None
     if prof:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    if _wino4_case(h, w, kh, dil, cin, cout, cin_w) and cout >= 16:
-        name = "wino4 wgrad (input x2 + gemm + output)"
-        ws = _workspace4(lib.runet_wino4_wgrad_workspace_floats(n, h, w, cin, cout), x.device)
-        check(lib.runet_wino4_wgrad(x.data_ptr(), ld(x), dy.data_ptr(), ld(dy), out.data_ptr(), ws.data_ptr(), ws.numel(), n, h, w, cin, cout, stream()))
-    elif USE_WINOGRAD and kh == 3 and dil == 1 and cin_w == cin and h % 2 == 0 and w % 2 == 0 and cin >= 16:
+    if USE_WINOGRAD and kh == 3 and dil == 1 and cin_w == cin and h % 2 == 0 and w % 2 == 0 and cin >= 16:
         name = "wino_wgrad_kernel(+reduce)"
         nws = lib.runet_wino_wgrad_workspace_floats(n, h, w, cin, cout)
         ws = workspace(nws, x.device)
@@ -370,28 +368,67 @@ def wino4_weights(w_hwio, dgrad=False):
     return U
 
 
-def wino4_conv(x, U, bias=None, out=None, accumulate=False):
+def wino4_conv(x, U, bias=None, out=None, accumulate=False, keep_v=None):
+    """keep_v: dict that receives {"V": transformed input [36*T*K]} - the weight gradient of the same convolution reuses it
+    (conv_wgrad(..., v=...)) instead of transforming x again."""
     n, h, w, k = x.shape
     nn_ = U.shape[2]
     if out is None:
         out = empty_nhwc(n, h, w, nn_, x)
-    ws = _workspace4(lib.runet_wino4_workspace_floats(n, h, w, k, nn_), x.device)
+    bp = bias.data_ptr() if bias is not None else None
+    t = n * (h // 4) * (w // 4)
+    if _PROFILE is None and keep_v is None:
+        ws = _workspace4(lib.runet_wino4_workspace_floats(n, h, w, k, nn_), x.device)
+        check(lib.runet_wino4_conv(x.data_ptr(), ld(x), U.data_ptr(), bp, out.data_ptr(), ld(out), n, h, w, k, nn_, int(accumulate), ws.data_ptr(),
+                                   ws.numel(), stream()))
+        return out
+    # the same three kernels through their own entry points (V kept for the backward pass / HIP events around the position-GEMM alone)
+    if keep_v is not None:
+        vt = torch.empty(36 * t * k, device=x.device, dtype=torch.float32)
+        keep_v["V"] = vt
+        V, M = vt.data_ptr(), _workspace4(36 * t * nn_, x.device).data_ptr()
+    else:
+        ws = _workspace4(36 * t * (k + nn_), x.device)
+        V, M = ws.data_ptr(), ws.data_ptr() + 4 * 36 * t * k
+    check(lib.runet_wino4_input(x.data_ptr(), ld(x), k, n, h, w, 0, V, stream()))
     if _PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(lib.runet_wino4_conv(x.data_ptr(), ld(x), U.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(), ld(out),
-                               n, h, w, k, nn_, int(accumulate), ws.data_ptr(), ws.numel(), stream()))
+    check(lib.runet_gemm_batched(V, k, t * k, U.data_ptr(), k * nn_, M, nn_, t * nn_, 36, t, k, nn_, stream()))
     if _PROFILE is not None:
         e1.record()
-        _PROFILE.append(("wino4 (input+gemm+output)", 2.0 * n * h * w * 9 * k * nn_, e0, e1))
+        _PROFILE.append(("gemm_nn_kernel", 2.0 * 36 * t * k * nn_, e0, e1))
+    check(lib.runet_wino4_output(M, nn_, n, h, w, bp, out.data_ptr(), ld(out), int(accumulate), stream()))
     return out
 
 
-def wino4_wgrad(x, dy, out=None):
+def wino4_wgrad(x, dy, out=None, v=None):
+    """v: the forward pass's transformed input (wino4_conv(keep_v=...)) - skips the B^T d B pass over x."""
     n, h, w, cin = x.shape
     cout = dy.shape[3]
     if out is None:
         out = torch.empty((3, 3, cin, cout), device=x.device, dtype=torch.float32)
     ws = _workspace4(lib.runet_wino4_wgrad_workspace_floats(n, h, w, cin, cout), x.device)
-    check(lib.runet_wino4_wgrad(x.data_ptr(), ld(x), dy.data_ptr(), ld(dy), out.data_ptr(), ws.data_ptr(), ws.numel(), n, h, w, cin, cout, stream()))
+    if _PROFILE is None and v is None:
+        check(lib.runet_wino4_wgrad(x.data_ptr(), ld(x), dy.data_ptr(), ld(dy), out.data_ptr(), ws.data_ptr(), ws.numel(), n, h, w, cin, cout, stream()))
+        return out
+    t = n * (h // 4) * (w // 4)
+    V = ws.data_ptr()
+    Z = V + 4 * 36 * t * cin
+    dU = Z + 4 * 36 * t * cout
+    rps = lib.runet_wino4_wgrad_rows_per_split(n, h, w, cin, cout)
+    if v is None:
+        check(lib.runet_wino4_input(x.data_ptr(), ld(x), cin, n, h, w, 0, V, stream()))
+    else:
+        assert v.numel() == 36 * t * cin
+        V = v.data_ptr()
+    check(lib.runet_wino4_input(dy.data_ptr(), ld(dy), cout, n, h, w, 1, Z, stream()))
+    if _PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(lib.runet_gemm_tn_batched(V, cin, t * cin, Z, cout, t * cout, dU, 36, t, cin, cout, rps, stream()))
+    if _PROFILE is not None:
+        e1.record()
+        _PROFILE.append(("gemm_tn_kernel", 2.0 * 36 * t * cin * cout, e0, e1))
+    check(lib.runet_wino4_wgrad_output(dU, -(-t // rps), cin, cout, out.data_ptr(), stream()))
     return out

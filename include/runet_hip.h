@@ -181,6 +181,14 @@ long runet_wino4_workspace_floats(int n_img, int h, int w, int k, int n);
 int runet_wino4_weights(const float* w_hwio, float* U, int cin, int cout, int dgrad, void* stream);
 int runet_wino4_conv(const float* x, int ldx, const float* U, const float* bias, float* y, int ldy, int n_img, int h, int w, int k, int n,
                      int accumulate, float* workspace, long workspace_floats, void* stream);
+/* the stages of the two composites below, one kernel each (T = n_img*(h/4)*(w/4) tiles):
+ *   runet_wino4_input  mode 0: V[36][T][c] = B^T d B (6x6 patches of src, stride 4, 1-pixel halo); mode 1: Z[36][T][c] = A dY A^T (4x4 tiles)
+ *   runet_gemm_batched / runet_gemm_tn_batched: the 36 position-GEMMs
+ *   runet_wino4_output: y = A^T M A (+bias, +y);  runet_wino4_wgrad_output: dw[3][3][cin][cout] = G^T (sum_splits dU[split][36][cin][cout]) G */
+int runet_wino4_input(const float* src, int ld, int c, int n_img, int h, int w, int mode, float* V, void* stream);
+int runet_wino4_output(const float* M, int n, int n_img, int h, int w, const float* bias, float* y, int ldy, int accumulate, void* stream);
+int runet_wino4_wgrad_output(const float* dU, int splits, int cin, int cout, float* dw, void* stream);
+int runet_wino4_wgrad_rows_per_split(int n_img, int h, int w, int cin, int cout);
 long runet_wino4_wgrad_workspace_floats(int n_img, int h, int w, int cin, int cout);
 int runet_wino4_wgrad(const float* x, int ldx, const float* dy, int ldy, float* dw, float* workspace, long workspace_floats, int n_img, int h, int w,
                       int cin, int cout, void* stream);

@@ -1,0 +1,135 @@
+"""GPU: the hot path at BASELINE.json's FULL sizes, checked through size-independent properties (the oracle needs ~10 s per
+16 x 256 x 256 step, so it is used here only on a 2-image slice):
+  * eval mode: a batch equals its images run one by one (BN on running statistics, no cross-image coupling) - config 2
+    (16 x 256^2), config 3's per-GPU shard (4 x 512^2) and config 5's tile (1 x 1024^2);
+  * two identical train steps are bit-identical (every reduction in the path has a fixed order) and the gradient of 2*loss is
+    exactly 2x the gradient of loss (linearity of the whole backward; scaling by 2 is exact in fp32);
+  * the gradient agrees with a central finite difference of the loss along the gradient direction (backward vs forward, no oracle);
+  * a 2 x 256^2 train step against the CPU oracle: logits/probabilities within 1e-3, IoU within 0.001 (north_star tolerances).
+"""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _model(pkg, oracle, seed=21, base=64):
+    m = pkg.RobustUNet(3, 1, base)
+    m.load_state_dict(oracle.init_state(3, 1, base, seed=seed, perturb_bn=True))
+    return m.to(DEV)
+
+
+@pytest.mark.parametrize("n,size", [(16, 256), (4, 512), (1, 1024)])
+def test_eval_batch_equals_single_images(pkg, oracle, n, size):
+    model = _model(pkg, oracle).eval()
+    x, _ = pkg.synthetic_batch(n, size, seed=31)
+    x = x.to(DEV)
+    with torch.no_grad():
+        full = model(x)
+        assert full.shape == (n, 1, size, size) and bool(torch.isfinite(full).all())
+        if n == 1:      # one image: compare against its four quadrant-independent re-run (determinism) instead
+            assert torch.equal(full, model(x))
+            return
+        for i in (0, n // 2, n - 1):
+            one = model(x[i:i + 1])
+            # the per-image result may differ in the last bits (tile shapes of the GEMMs depend on the pixel count)
+            np.testing.assert_allclose(one.cpu().numpy(), full[i:i + 1].cpu().numpy(), rtol=0, atol=2e-5)
+
+
+def _step_grads(pkg, model, x, y, scale=1.0):
+    for p in model.parameters():
+        p.grad = None
+    prob = model(x)
+    loss = pkg.bce_loss(prob, y)
+    (loss * scale).backward()
+    return loss.detach(), [p.grad.detach().clone() for p in model.parameters()], prob.detach()
+
+
+def test_full_size_step_is_deterministic_and_linear(pkg, oracle):
+    n, size = 16, 256
+    model = _model(pkg, oracle).train()
+    model.set_dropout_masks({k: v.to(DEV) for k, v in oracle.dropout_masks(n, 64, seed=5).items()})
+    x, y = pkg.synthetic_batch(n, size, seed=33)
+    x, y = x.to(DEV), y.to(DEV)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    l1, g1, p1 = _step_grads(pkg, model, x, y)
+    model.load_state_dict(sd)                      # restore BN running statistics
+    l2, g2, p2 = _step_grads(pkg, model, x, y)
+    assert torch.equal(p1, p2) and torch.equal(l1, l2)
+    for a, b in zip(g1, g2):
+        assert torch.equal(a, b)
+    model.load_state_dict(sd)
+    _, g3, _ = _step_grads(pkg, model, x, y, scale=2.0)
+    for a, b in zip(g1, g3):
+        assert torch.equal(a * 2.0, b)
+
+
+def test_full_size_gradient_matches_finite_difference(pkg, oracle):
+    n, size = 16, 256
+    model = pkg.RobustUNet(3, 1, 64)
+    st = oracle.init_state(3, 1, 64, seed=22, perturb_bn=False)
+    # small output weights keep the logits away from fp32 sigmoid saturation (1 - p == 0 -> the BCE clamp at -100 makes the loss
+    # JUMP when a pixel crosses |logit| ~ 17; at the fan_out-normal initialisation ~4 % of the pixels sit there and a finite
+    # difference measures those jumps, oracle included)
+    st["outc.0.weight"] = st["outc.0.weight"] * 0.02
+    model.load_state_dict(st)
+    model = model.to(DEV).train()
+    model.set_dropout_masks({k: v.to(DEV) for k, v in oracle.dropout_masks(n, 64, seed=6).items()})
+    x, y = pkg.synthetic_batch(n, size, seed=34)
+    x, y = x.to(DEV), y.to(DEV)
+    named = list(model.named_parameters())
+    _, g, prob = _step_grads(pkg, model, x, y)
+    assert 0.02 < float(prob.min()) and float(prob.max()) < 0.98
+    # direction = the gradient of every parameter EXCEPT the output layer (which alone carries half of |g|^2 here and would mask
+    # an error in the deep backward)
+    d = [torch.zeros_like(t) if k.startswith("outc.") else t for (k, _), t in zip(named, g)]
+    dn2 = sum(float((t.double() ** 2).sum()) for t in d)
+    eps = 5e-4 / dn2                       # loss moves by ~5e-4 per side: >> fp32 noise of a 1M-pixel mean, second-order term < 1 %
+
+    def loss_at(sign):
+        with torch.no_grad():
+            for (_, p), t in zip(named, d):
+                p.add_(t, alpha=sign * eps)
+            val = float(pkg.bce_loss(model(x), y))
+            for (_, p), t in zip(named, d):
+                p.add_(t, alpha=-sign * eps)
+        return val
+
+    fd = (loss_at(+1.0) - loss_at(-1.0)) / (2 * eps)
+    assert abs(fd - dn2) <= 3e-2 * dn2, (fd, dn2)
+
+
+def test_two_full_size_tiles_against_the_oracle(pkg, oracle):
+    n, size, seed = 2, 256, 41
+    torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
+    model = _model(pkg, oracle, seed=seed).train()
+    masks = oracle.dropout_masks(n, 64, seed=seed)
+    model.set_dropout_masks({k: v.to(DEV) for k, v in masks.items()})
+    x, y = pkg.synthetic_batch(n, size, seed=seed)
+    prob, logit = model(x.to(DEV), return_logits=True)
+    loss = pkg.bce_loss(prob, y.to(DEV))
+    loss.backward()
+    P = oracle.init_state(3, 1, 64, seed=seed, perturb_bn=True)
+    names = oracle.param_names(3, 1, 64)
+    for k in names:
+        P[k].requires_grad_(True)
+    rp, rl = oracle.forward(P, x, True, masks)
+    rloss = oracle.bce_mean(rp, y)
+    rloss.backward()
+    np.testing.assert_allclose(prob.detach().cpu().numpy(), rp.detach().numpy(), rtol=0, atol=1e-3)
+    lg = rl.detach().numpy()
+    np.testing.assert_allclose(logit.detach().cpu().numpy(), lg, rtol=1e-3, atol=1e-3 * max(1.0, float(np.abs(lg).max()) / 10))
+    assert abs(float(loss.detach()) - float(rloss.detach())) <= 1e-3 * max(1.0, abs(float(rloss.detach())))
+    ev = pkg.ModelEvaluator(torch.device(DEV))
+    for i in range(n):
+        a = ev.calculate_metrics(prob[i, 0].detach(), y[i, 0].to(DEV))
+        b = oracle.seg_metrics(rp[i, 0].detach(), y[i, 0])
+        assert abs(a["iou"] - b["iou"]) <= 1e-3 and abs(a["f1_score"] - b["f1_score"]) <= 1e-3
+    gn = np.array([p.grad.double().norm().item() for p in model.parameters()])
+    rn = np.array([P[k].grad.double().norm().item() for k in names])
+    rel = np.abs(gn - rn) / (rn + 1e-3 * rn.max())
+    assert rel.max() < 2e-2, (names[int(rel.argmax())], gn[int(rel.argmax())], rn[int(rel.argmax())])
