@@ -43,6 +43,14 @@ int runet_gemm_nn_launch(const float* a, int lda, long sa, const float* b, long 
 int runet_gemm_tn_launch(const float* a, int lda, long sa, const float* b, int ldb, long sb, float* c, int batch, int rows, int k, int n, int rps,
                          hipStream_t st);
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a full workgroup fence, which on gfx9 drains vmcnt too:
+// every global load still in flight (register prefetches meant to overlap the next phase) is waited for at the barrier.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // ---- wave / block reductions (wave = 64 lanes) ----
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
