@@ -221,6 +221,44 @@ extern "C" int runet_bce_bwd(const float* prob, const float* target, const float
 
 extern "C" int runet_adam_chunk_elems(void) { return ADAM_CHUNK; }
 
+// ---- graph-capturable form: hyper-parameters and the step counter live in device memory, so a captured launch stays valid when
+// the learning rate changes or the step advances.  hyper = {lr, beta1, beta2, eps, weight_decay, grad_scale}.
+namespace {
+__global__ void adam_tick_kernel(int* step) { *step += 1; }
+__global__ __launch_bounds__(TPB) void adam_multi_dev_kernel(const long long* __restrict__ table, int T, const int* __restrict__ chunks,
+                                                             const float* __restrict__ hyper, const int* __restrict__ step_dev) {
+    const int t = chunks[blockIdx.x * 2], ck = chunks[blockIdx.x * 2 + 1];
+    float* p = reinterpret_cast<float*>(table[t]);
+    const float* g = reinterpret_cast<const float*>(table[T + t]);
+    float* m = reinterpret_cast<float*>(table[2 * T + t]);
+    float* v = reinterpret_cast<float*>(table[3 * T + t]);
+    const long n = table[4 * T + t];
+    const long beg = (long)ck * ADAM_CHUNK;
+    const long end = beg + ADAM_CHUNK < n ? beg + ADAM_CHUNK : n;
+    const float lr = hyper[0], beta1 = hyper[1], beta2 = hyper[2], eps = hyper[3], wd = hyper[4], grad_scale = hyper[5];
+    const int st = *step_dev;
+    const float bc1 = (float)(1.0 - pow((double)beta1, (double)st));           // same double-precision corrections as the host form
+    const float bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)st));
+    const float step = lr / bc1;
+    for (long o = beg + threadIdx.x; o < end; o += TPB) {
+        float pv = p[o], mv = m[o], vv = v[o];
+        const float gv = g[o] * grad_scale + wd * pv;
+        mv = beta1 * mv + (1.f - beta1) * gv;
+        vv = beta2 * vv + (1.f - beta2) * gv * gv;
+        pv -= step * mv / (sqrtf(vv) / bc2_sqrt + eps);
+        p[o] = pv; m[o] = mv; v[o] = vv;
+    }
+}
+}  // namespace
+
+extern "C" int runet_adam_multi_dev(const long long* table, int n_tensors, const int* chunks, int n_chunks, const float* hyper, int* step_dev,
+                                    void* stream) {
+    RUNET_REQUIRE(table && chunks && hyper && step_dev && n_tensors > 0 && n_chunks > 0, "bad arguments");
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev);
+    hipLaunchKernelGGL(adam_multi_dev_kernel, dim3(n_chunks), dim3(TPB), 0, (hipStream_t)stream, table, n_tensors, chunks, hyper, step_dev);
+    RUNET_CHECK_LAUNCH();
+}
+
 extern "C" int runet_adam_multi(const long long* table, int n_tensors, const int* chunks, int n_chunks, float lr, float beta1, float beta2,
                                 float eps, float weight_decay, int step, float grad_scale, void* stream) {
     RUNET_REQUIRE(table && chunks && n_tensors > 0 && n_chunks > 0 && step >= 1, "bad arguments");

@@ -25,6 +25,33 @@ class FusedAdam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._tables = {}
         self.grad_scale = 1.0     # multiplied into the gradient (1/world_size after a SUM all-reduce)
+        self.capturable = False   # True: hyper-parameters and the step counter are read from device memory (hipGraph replay, trainer.TrainStep)
+        self._dev_state = {}      # group index -> (hyper float[6], step int32[1], host copy of hyper)
+
+    def _device_hyper(self, gi, group, dev, step_host):
+        b1, b2 = group["betas"]
+        want = (float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]), float(self.grad_scale))
+        st = self._dev_state.get(gi)
+        if st is None:
+            st = [torch.tensor(want, dtype=torch.float32, device=dev), torch.tensor([step_host], dtype=torch.int32, device=dev), want]
+            self._dev_state[gi] = st
+        elif st[2] != want:       # e.g. ReduceLROnPlateau changed lr: an ordinary stream-ordered copy, issued OUTSIDE any capture
+            st[0].copy_(torch.tensor(want, dtype=torch.float32), non_blocking=False)
+            st[2] = want
+        return st
+
+    def sync_hyper(self):
+        """Refresh the device copy of the hyper-parameters (call before replaying a captured step)."""
+        for gi, group in enumerate(self.param_groups):
+            plist = [p for p in group["params"] if p.grad is not None or p in self.state]
+            if plist:
+                self._device_hyper(gi, group, plist[0].device, self.state[plist[0]].get("step", 0) if plist[0] in self.state else 0)
+
+    def advance_host_step(self):
+        """A graph replay advanced the device step counter: keep the host-side `state[p]["step"]` (state_dict) in line."""
+        for st in self.state.values():
+            if "step" in st:
+                st["step"] += 1
 
     def _table(self, gi, plist):
         key_ptrs = tuple(t.data_ptr() for p in plist for t in (p, p.grad, self.state[p]["exp_avg"], self.state[p]["exp_avg_sq"]))
@@ -68,6 +95,17 @@ class FusedAdam(torch.optim.Optimizer):
                 st["step"] += 1
             step = self.state[plist[0]]["step"]
             d_tab, d_chunks, n_chunks = self._table(gi, plist)
+            if self.capturable:
+                capturing = torch.cuda.is_current_stream_capturing()
+                if capturing:     # the captured launch must not depend on host state: no hyper refresh, the replay driver counts steps
+                    for p in plist:
+                        self.state[p]["step"] -= 1
+                    hyper, step_dev, _ = self._dev_state[gi]
+                else:
+                    hyper, step_dev, _ = self._device_hyper(gi, group, plist[0].device, step - 1)
+                check(lib.runet_adam_multi_dev(d_tab.data_ptr(), len(plist), d_chunks.data_ptr(), n_chunks, hyper.data_ptr(), step_dev.data_ptr(),
+                                               torch.cuda.current_stream().cuda_stream))
+                continue
             b1, b2 = group["betas"]
             check(lib.runet_adam_multi(d_tab.data_ptr(), len(plist), d_chunks.data_ptr(), n_chunks, float(group["lr"]), float(b1), float(b2),
                                        float(group["eps"]), float(group["weight_decay"]), int(step), float(self.grad_scale),

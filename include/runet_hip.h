@@ -162,6 +162,10 @@ int runet_adam_chunk_elems(void);
 int runet_adam_multi(const long long* table, int n_tensors, const int* chunks, int n_chunks, float lr, float beta1, float beta2, float eps,
                      float weight_decay, int step, float grad_scale, void* stream);
 
+/* hipGraph-capturable form: hyper = device float[6] {lr, beta1, beta2, eps, weight_decay, grad_scale}; *step_dev is incremented on the
+ * device and then used for the bias corrections, so one captured launch serves every step and every learning rate. */
+int runet_adam_multi_dev(const long long* table, int n_tensors, const int* chunks, int n_chunks, const float* hyper, int* step_dev, void* stream);
+
 /* ---- ModelEvaluator.calculate_metrics counts (Main_Final.py:519-547): counts[n] = {tp, pred>thr, target!=0, agree} ---- */
 int runet_seg_counts(const float* pred, const float* target, long long* counts, int n_img, long per_img, float threshold, void* stream);
 

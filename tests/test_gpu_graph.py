@@ -1,0 +1,68 @@
+"""GPU: the hipGraph-captured train step (trainer.TrainStep(graph=True), BASELINE.json config 5's "hipGraph-captured step") replays
+exactly what the eager step launches: same losses, bit-identical parameters, Adam's device-side step counter and learning rate
+follow the host optimizer (LR schedulers keep working without re-capture)."""
+import importlib
+import time
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _make(pkg, oracle, graph):
+    trainer = importlib.import_module("eusipco-2026-robust-unet_amd.trainer")
+    m = pkg.RobustUNet(3, 1, 16)
+    m.load_state_dict(oracle.init_state(3, 1, 16, seed=4, perturb_bn=True))
+    m = m.to(DEV).train()
+    m.set_dropout_masks({k: v.to(DEV) for k, v in oracle.dropout_masks(2, 16, seed=4).items()})
+    step = trainer.TrainStep(m, lr=1e-3, weight_decay=1e-4, graph=graph, graph_warmup=2)
+    step.optimizer.capturable = True          # both sides on the device-hyper Adam kernel: the comparison can be bitwise
+    return m, step
+
+
+def test_graph_step_equals_eager_step(pkg, oracle):
+    ma, sa = _make(pkg, oracle, graph=False)
+    mb, sb = _make(pkg, oracle, graph=True)
+    batches = [pkg.synthetic_batch(2, 64, seed=50 + i) for i in range(7)]
+    for i, (x, y) in enumerate(batches):
+        if i == 5:                             # an LR scheduler acting between steps
+            for st in (sa, sb):
+                st.optimizer.param_groups[0]["lr"] = 2.5e-4
+        x, y = x.to(DEV), y.to(DEV)
+        la, lb = sa(x, y), sb(x, y)
+        assert torch.equal(la.detach(), lb.detach()), (i, float(la), float(lb))
+    assert sb._graph is not None
+    for (k, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+        assert torch.equal(pa, pb), k
+    for (k, ba), (_, bb) in zip(ma.named_buffers(), mb.named_buffers()):
+        assert torch.equal(ba, bb), k
+    steps = {st["step"] for st in sb.optimizer.state.values()}
+    assert steps == {7}
+    # a different batch shape falls back to an ordinary step
+    mb.set_dropout_masks(None)                 # the injected masks are for 2 images
+    x, y = pkg.synthetic_batch(1, 64, seed=99)
+    assert torch.isfinite(sb(x.to(DEV), y.to(DEV)))
+
+
+def test_graph_step_removes_launch_overhead(pkg, oracle):
+    trainer = importlib.import_module("eusipco-2026-robust-unet_amd.trainer")
+    out = {}
+    for graph in (False, True):
+        torch.manual_seed(0)
+        m = pkg.RobustUNet(3, 1, 64).to(DEV).train()
+        step = trainer.TrainStep(m, graph=graph)
+        x, y = pkg.synthetic_batch(2, 256, seed=1)
+        x, y = x.to(DEV), y.to(DEV)
+        for _ in range(5):
+            step(x, y)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            loss = step(x, y)
+        torch.cuda.synchronize()
+        out[graph] = (time.perf_counter() - t0) / 20
+        assert torch.isfinite(loss)
+    print(f"\n2 x 256x256 train step: eager {out[False] * 1e3:.2f} ms, hipGraph {out[True] * 1e3:.2f} ms")
+    assert out[True] < out[False] * 1.05
