@@ -23,6 +23,11 @@ import torch
 import torch.distributed as dist
 
 
+def _ops():
+    from . import ops
+    return ops
+
+
 class GradAllReducer:
     def __init__(self, model, bucket_floats=8 << 20, process_group=None, average_in_optimizer=True, sync_bn=False):
         if not dist.is_initialized():
@@ -68,6 +73,9 @@ class GradAllReducer:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             self.comm_stream.wait_event(ev)
+            side = _ops().side_stream()            # weight gradients of the slice may still be running on the side stream
+            if side is not None:
+                self.comm_stream.wait_stream(side)
             with torch.cuda.stream(self.comm_stream):
                 dist.all_reduce(sl, op=dist.ReduceOp.SUM, group=self.group)
                 if not self.average_in_optimizer:

@@ -501,6 +501,11 @@ class GradArena:
 
 def net_backward(C, dprob, sink, done=lambda blk: None):
     """Explicit backward pass; parameter gradients are written through `sink` (GradArena or DictSink)."""
+    with ops.wgrad_side_stream():
+        _net_backward(C, dprob, sink, done)
+
+
+def _net_backward(C, dprob, sink, done):
     y, w, prob = C["head"]
     dy = B.outc_backward(dprob, prob, y, w, sink, pre="outc.0.")
     done("outc.0")

@@ -35,7 +35,7 @@ def empty_nhwc(n, h, w, c, like):
 
 
 def workspace(nfloats, device):
-    key = (device.index, "wgrad")
+    key = (device.index, "wgrad", torch.cuda.current_stream().cuda_stream)      # one scratch per stream (weight gradients may run on a side stream)
     buf = _ws.get(key)
     if buf is None or buf.numel() < nfloats:
         buf = torch.empty(max(nfloats, 1 << 22), device=device, dtype=torch.float32)
@@ -171,7 +171,57 @@ def conv_dgrad(dy, w_hwio, out=None, dil=1, accumulate=False):
     return out
 
 
+# ---- weight gradients on a side stream: nothing in the backward chain waits for them (only the optimizer / the gradient all-reduce do),
+# and they are matrix-core work while much of the chain (BatchNorm / attention backward, Winograd transforms) is HBM-bound.
+USE_WGRAD_STREAM = os.environ.get("RUNET_NO_WGRAD_STREAM", "0") != "1"
+_side = {}
+
+
+class wgrad_side_stream:
+    """with ops.wgrad_side_stream(): ...backward...  -> conv_wgrad / convt_wgrad launch on a second HIP stream that waits for their inputs;
+    leaving the block makes the current stream wait for it.  ops.side_stream() is the active stream (the all-reduce must wait for it too)."""
+
+    def __enter__(self):
+        if USE_WGRAD_STREAM and torch.cuda.is_available():        # under hipGraph capture the fork / join is captured with everything else
+            dev = torch.cuda.current_device()
+            if ("s", dev) not in _side:
+                _side[("s", dev)] = torch.cuda.Stream(device=dev)
+            _side["active"] = _side[("s", dev)]
+        return self
+
+    def __exit__(self, *exc):
+        s = _side.pop("active", None)
+        if s is not None:
+            torch.cuda.current_stream().wait_stream(s)
+        return False
+
+
+def side_stream():
+    return _side.get("active")
+
+
+def _on_side(fn, tensors):
+    s = _side.get("active")
+    if s is None:
+        return fn()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        r = fn()
+    for t in tensors:
+        if t is not None:
+            t.record_stream(s)
+    return r
+
+
 def conv_wgrad(x, dy, kh, kw, cin_w=None, dil=1, out=None, v=None):
+    if _side.get("active") is not None:
+        if out is None:
+            out = torch.empty((kh, kw, x.shape[3] if cin_w is None else cin_w, dy.shape[3]), device=x.device, dtype=torch.float32)
+        return _on_side(lambda: _conv_wgrad(x, dy, kh, kw, cin_w, dil, out, v), (x, dy, out, v))
+    return _conv_wgrad(x, dy, kh, kw, cin_w, dil, out, v)
+
+
+def _conv_wgrad(x, dy, kh, kw, cin_w=None, dil=1, out=None, v=None):
     n, h, w, cin = x.shape
     cout = dy.shape[3]
     cin_w = cin if cin_w is None else cin_w
@@ -222,6 +272,14 @@ def convt_dgrad(dy, w_hwio, out=None, accumulate=False):
 
 
 def convt_wgrad(x, dy, out=None):
+    if _side.get("active") is not None:
+        if out is None:
+            out = torch.empty((2, 2, x.shape[3], dy.shape[3]), device=x.device, dtype=torch.float32)
+        return _on_side(lambda: _convt_wgrad(x, dy, out), (x, dy, out))
+    return _convt_wgrad(x, dy, out)
+
+
+def _convt_wgrad(x, dy, out=None):
     n, h, w, cin = x.shape
     cout = dy.shape[3]
     if out is None:
@@ -348,10 +406,11 @@ _ws4 = {}
 
 
 def _workspace4(nfloats, device):
-    buf = _ws4.get(device.index)
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    buf = _ws4.get(key)
     if buf is None or buf.numel() < nfloats:
         buf = torch.empty(int(nfloats), device=device, dtype=torch.float32)
-        _ws4[device.index] = buf
+        _ws4[key] = buf
     return buf
 
 
