@@ -21,11 +21,22 @@ struct GemmArgs {
     int rps;            // TN: rows per split (multiple of 16)
 };
 
-constexpr int BK = 16;
-constexpr int NN_LDA = BK + 4, NN_LDB = 128 + 4;
-constexpr int NN_A = 128 * NN_LDA, NN_B = BK * NN_LDB, NN_STAGE = NN_A + NN_B;
+constexpr int BK = 16;            // TN kernel k-step (rows per stage)
 
+// NN kernel: KB-deep k-steps (16: three LDS stages, 32: two fragment sets still, half the barriers per FLOP)
+template <int KB>
+struct NNCfg {
+    static constexpr int LDA = KB + 4, LDB = 128 + 4;
+    static constexpr int A = 128 * LDA, B = KB * LDB, STAGE = A + B;
+    static constexpr int AQ = KB / 4;                 // float4 per A row
+    static constexpr int AV = 128 * AQ / 256;         // A float4 loads per thread
+    static constexpr int BV = KB * 32 / 256;          // B float4 loads per thread
+    static constexpr int NKH = KB / 8;                // 8-deep fragment groups per step
+};
+
+template <int KB>
 __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(GemmArgs g) {
+    using C = NNCfg<KB>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm0 = (wid >> 1) * 64, wn0 = (wid & 1) * 64;
@@ -33,42 +44,43 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(GemmArgs g) {
     const int m0 = blockIdx.x * 128, n0 = blockIdx.y * 128;
     const float* A = g.a + (long)blockIdx.z * g.sa;
     const float* B = g.b + (long)blockIdx.z * g.sb;
-    float* C = g.c + (long)blockIdx.z * g.sc;
+    float* Cc = g.c + (long)blockIdx.z * g.sc;
 
-    // ---- loaders: A item (row, k-quad) = (tid >> 2 (+64), tid & 3);  B item (k-row, n-quad) = (tid >> 5 (+8), tid & 31)
-    const int akq = tid & 3, bnq = tid & 31;
-    long aoff[2]; bool aok[2];
+    // ---- loaders: A item (row, k-quad) = (tid / AQ (+256/AQ per pass), tid % AQ);  B item (k-row, n-quad) = (tid >> 5 (+8), tid & 31)
+    const int akq = tid % C::AQ, arow = tid / C::AQ, bnq = tid & 31;
+    constexpr int ARSTEP = 256 / C::AQ;
+    long aoff[C::AV]; bool aok[C::AV];
 #pragma unroll
-    for (int v = 0; v < 2; ++v) {
-        const int r = m0 + (tid >> 2) + 64 * v;
+    for (int v = 0; v < C::AV; ++v) {
+        const int r = m0 + arow + ARSTEP * v;
         aok[v] = r < g.rows;
         aoff[v] = (long)(aok[v] ? r : 0) * g.lda + akq * 4;
     }
     const bool bn_ok = n0 + bnq * 4 < g.n;
     const int bcol = bn_ok ? n0 + bnq * 4 : 0;
-    f32x4 ra[2], rb[2];
-    bool oka[2], okb[2];              // validity of the tile held in ra/rb (applied at the LDS store, so the loads stay in flight)
+    f32x4 ra[C::AV], rb[C::BV];
+    bool oka[C::AV], okb[C::BV];      // validity of the tile held in ra/rb (applied at the LDS store, so the loads stay in flight)
     auto load_tile = [&](int kofs) {
 #pragma unroll
-        for (int v = 0; v < 2; ++v) {
+        for (int v = 0; v < C::AV; ++v) {
             oka[v] = aok[v] && kofs + akq * 4 < g.k;
             ra[v] = *reinterpret_cast<const f32x4*>(A + (oka[v] ? aoff[v] + kofs : 0));
         }
 #pragma unroll
-        for (int v = 0; v < 2; ++v) {
+        for (int v = 0; v < C::BV; ++v) {
             const int kr = kofs + (tid >> 5) + 8 * v;
             okb[v] = bn_ok && kr < g.k;
             rb[v] = *reinterpret_cast<const f32x4*>(B + (okb[v] ? (long)kr * g.ldb + bcol : 0));
         }
     };
     auto store_tile = [&](int buf) {
-        float* As = smem + buf * NN_STAGE;
-        float* Bs = As + NN_A;
+        float* As = smem + buf * C::STAGE;
+        float* Bs = As + C::A;
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int v = 0; v < 2; ++v) *reinterpret_cast<f32x4*>(As + ((tid >> 2) + 64 * v) * NN_LDA + akq * 4) = oka[v] ? ra[v] : zero;
+        for (int v = 0; v < C::AV; ++v) *reinterpret_cast<f32x4*>(As + (arow + ARSTEP * v) * C::LDA + akq * 4) = oka[v] ? ra[v] : zero;
 #pragma unroll
-        for (int v = 0; v < 2; ++v) *reinterpret_cast<f32x4*>(Bs + ((tid >> 5) + 8 * v) * NN_LDB + bnq * 4) = okb[v] ? rb[v] : zero;
+        for (int v = 0; v < C::BV; ++v) *reinterpret_cast<f32x4*>(Bs + ((tid >> 5) + 8 * v) * C::LDB + bnq * 4) = okb[v] ? rb[v] : zero;
     };
 
     f32x16 acc[2][2];
@@ -81,14 +93,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(GemmArgs g) {
 
     struct Frag { f32x4 a[2]; float b[2][4]; };
     auto read_frag = [&](int buf, int kh, Frag& f) {
-        const float* As = smem + buf * NN_STAGE;
-        const float* Bs = As + NN_A;
+        const float* As = smem + buf * C::STAGE;
+        const float* Bs = As + C::A;
 #pragma unroll
-        for (int a = 0; a < 2; ++a) f.a[a] = *reinterpret_cast<const f32x4*>(As + (wm0 + a * 32 + li) * NN_LDA + kh * 8 + 4 * lh);
+        for (int a = 0; a < 2; ++a) f.a[a] = *reinterpret_cast<const f32x4*>(As + (wm0 + a * 32 + li) * C::LDA + kh * 8 + 4 * lh);
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) f.b[b][q] = Bs[(kh * 8 + 4 * lh + q) * NN_LDB + wn0 + b * 32 + li];
+            for (int q = 0; q < 4; ++q) f.b[b][q] = Bs[(kh * 8 + 4 * lh + q) * C::LDB + wn0 + b * 32 + li];
     };
     auto mma = [&](const Frag& f) {
 #pragma unroll
@@ -99,30 +111,30 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(GemmArgs g) {
                 for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[a][q], f.b[b][q], acc[a][b], 0, 0, 0);
     };
 
-    const int nks = (g.k + BK - 1) / BK;
+    const int nks = (g.k + KB - 1) / KB;
     // prologue: tiles 0 and 1 into stages 0 and 1 (a k extent of one step loads an all-zero second tile: kofs >= k)
     load_tile(0);
     store_tile(0);
-    load_tile(BK);
+    load_tile(KB);
     store_tile(1);
     __syncthreads();
-    Frag f0, f1;
-    read_frag(0, 0, f0);
+    Frag f[2];
+    read_frag(0, 0, f[0]);
     __builtin_amdgcn_s_waitcnt(0xc07f);     // lgkmcnt(0): the loop header then merges two states with nothing outstanding
     int cur = 0;                      // stage holding tile s
     // The body is branch-free: past the end it re-loads zeros (kofs >= k), stores them into a stage nobody reads again and
     // prefetches fragments that are never multiplied, which keeps the compiler's waitcnt bookkeeping exact.
     for (int s = 0; s < nks; ++s) {
         const int nxt = cur == 2 ? 0 : cur + 1, nx2 = nxt == 2 ? 0 : nxt + 1;
-        load_tile((s + 2) * BK);
-        read_frag(cur, 1, f1);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(f0);
-        __builtin_amdgcn_sched_barrier(0);
-        read_frag(nxt, 0, f0);                      // tile s+1 became visible at the barrier that ended step s-1
-        __builtin_amdgcn_sched_barrier(0);
-        mma(f1);
-        __builtin_amdgcn_sched_barrier(0);
+        load_tile((s + 2) * KB);
+#pragma unroll
+        for (int kh = 0; kh < C::NKH; ++kh) {
+            if (kh + 1 < C::NKH) read_frag(cur, kh + 1, f[(kh + 1) & 1]);
+            else read_frag(nxt, 0, f[(kh + 1) & 1]);        // tile s+1 became visible at the barrier that ended step s-1
+            __builtin_amdgcn_sched_barrier(0);
+            mma(f[kh & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         store_tile(nx2);                            // stage of tile s-1: its last reads finished before the previous barrier
         __syncthreads();
         cur = nxt;
@@ -135,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(GemmArgs g) {
         for (int r = 0; r < 16; ++r) {
             const int row = m0 + wm0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             if (row < g.rows) {
-                float* crow = C + (long)row * g.ldc;
+                float* crow = Cc + (long)row * g.ldc;
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
                     const int col = n0 + wn0 + b * 32 + li;
@@ -265,7 +277,16 @@ int runet_gemm_nn_launch(const float* a, int lda, long sa, const float* b, long 
                          hipStream_t st) {
     GemmArgs g{};
     g.a = a; g.lda = lda; g.sa = sa; g.b = b; g.ldb = n; g.sb = sb; g.c = c; g.ldc = ldc; g.sc = sc; g.rows = rows; g.k = k; g.n = n;
-    hipLaunchKernelGGL(gemm_nn_kernel, dim3(cdiv(rows, 128), cdiv(n, 128), batch), dim3(256), 3 * NN_STAGE * sizeof(float), st, g);
+    static const int kb = getenv("RUNET_GEMM_KB") ? atoi(getenv("RUNET_GEMM_KB")) : 16;      // A/B switch for tools/bench_gemm.py
+    const dim3 grid(cdiv(rows, 128), cdiv(n, 128), batch);
+    if (kb == 32 && k % 32 == 0) {
+        static const bool ok = hipFuncSetAttribute((const void*)gemm_nn_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   3 * NNCfg<32>::STAGE * (int)sizeof(float)) == hipSuccess;
+        if (!ok) return 1;
+        hipLaunchKernelGGL(gemm_nn_kernel<32>, grid, dim3(256), 3 * NNCfg<32>::STAGE * sizeof(float), st, g);
+    } else {
+        hipLaunchKernelGGL(gemm_nn_kernel<16>, grid, dim3(256), 3 * NNCfg<16>::STAGE * sizeof(float), st, g);
+    }
     return 0;
 }
 
