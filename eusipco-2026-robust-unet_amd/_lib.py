@@ -11,6 +11,10 @@ import ctypes as C
 import os
 import re
 
+# The backward pass uses several HIP streams (main chain, weight gradients, gradient all-reduce + RCCL's own): with HIP's default of
+# 4 hardware queues they share queues and serialise on each other's event waits.  Only effective if the HIP runtime is not yet initialised.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import torch  # noqa: F401  (first: librunet_hip.so must bind to the HIP runtime that torch already loaded, not a second copy)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

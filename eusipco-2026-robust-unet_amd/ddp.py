@@ -48,6 +48,8 @@ class GradAllReducer:
     # -- wiring ------------------------------------------------------------------------------
     def attach(self, optimizer=None):
         """Hook the model's gradient arena; fold 1/world into the optimizer when it supports it."""
+        if not hasattr(self.model, "grad_arena"):
+            raise TypeError("GradAllReducer needs a model that exposes grad_arena() (RobustUNet); the DeepLabV3+ baseline is single-process")
         self.arena = self.model.grad_arena()
         self.arena.on_block_done = self._on_block_done
         if self.arena.flat.is_cuda and self.comm_stream is None:
