@@ -58,29 +58,31 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(GemmArgs g) {
     }
     const bool bn_ok = n0 + bnq * 4 < g.n;
     const int bcol = bn_ok ? n0 + bnq * 4 : 0;
-    f32x4 ra[C::AV], rb[C::BV];
-    bool oka[C::AV], okb[C::BV];      // validity of the tile held in ra/rb (applied at the LDS store, so the loads stay in flight)
-    auto load_tile = [&](int kofs) {
+    // One k-tile of raw global loads (validity applied at the LDS store, so the loads stay in flight).  TWO sets: the loads of tile
+    // s+3 are issued in step s and stored at the end of step s+1 - two whole steps (~5000 cycles) to arrive.  With one set (issued and
+    // stored in the same step) every step ended in a vmcnt wait for loads that take longer than a step under load: 58 % MFMA-busy.
+    struct Raw { f32x4 ra[C::AV], rb[C::BV]; bool oka[C::AV], okb[C::BV]; };
+    auto load_tile = [&](int kofs, Raw& R) {
 #pragma unroll
         for (int v = 0; v < C::AV; ++v) {
-            oka[v] = aok[v] && kofs + akq * 4 < g.k;
-            ra[v] = *reinterpret_cast<const f32x4*>(A + (oka[v] ? aoff[v] + kofs : 0));
+            R.oka[v] = aok[v] && kofs + akq * 4 < g.k;
+            R.ra[v] = *reinterpret_cast<const f32x4*>(A + (R.oka[v] ? aoff[v] + kofs : 0));
         }
 #pragma unroll
         for (int v = 0; v < C::BV; ++v) {
             const int kr = kofs + (tid >> 5) + 8 * v;
-            okb[v] = bn_ok && kr < g.k;
-            rb[v] = *reinterpret_cast<const f32x4*>(B + (okb[v] ? (long)kr * g.ldb + bcol : 0));
+            R.okb[v] = bn_ok && kr < g.k;
+            R.rb[v] = *reinterpret_cast<const f32x4*>(B + (R.okb[v] ? (long)kr * g.ldb + bcol : 0));
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf, const Raw& R) {
         float* As = smem + buf * C::STAGE;
         float* Bs = As + C::A;
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int v = 0; v < C::AV; ++v) *reinterpret_cast<f32x4*>(As + (arow + ARSTEP * v) * C::LDA + akq * 4) = oka[v] ? ra[v] : zero;
+        for (int v = 0; v < C::AV; ++v) *reinterpret_cast<f32x4*>(As + (arow + ARSTEP * v) * C::LDA + akq * 4) = R.oka[v] ? R.ra[v] : zero;
 #pragma unroll
-        for (int v = 0; v < C::BV; ++v) *reinterpret_cast<f32x4*>(Bs + ((tid >> 5) + 8 * v) * C::LDB + bnq * 4) = okb[v] ? rb[v] : zero;
+        for (int v = 0; v < C::BV; ++v) *reinterpret_cast<f32x4*>(Bs + ((tid >> 5) + 8 * v) * C::LDB + bnq * 4) = R.okb[v] ? R.rb[v] : zero;
     };
 
     f32x16 acc[2][2];
@@ -112,11 +114,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(GemmArgs g) {
     };
 
     const int nks = (g.k + KB - 1) / KB;
-    // prologue: tiles 0 and 1 into stages 0 and 1 (a k extent of one step loads an all-zero second tile: kofs >= k)
-    load_tile(0);
-    store_tile(0);
-    load_tile(KB);
-    store_tile(1);
+    // prologue: tiles 0 and 1 into stages 0 and 1 (a k extent of one step loads an all-zero second tile: kofs >= k), tile 2 in flight
+    Raw R0, R1;
+    load_tile(0, R0);
+    load_tile(KB, R1);
+    store_tile(0, R0);
+    store_tile(1, R1);
+    load_tile(2 * KB, R0);
     __syncthreads();
     Frag f[2];
     read_frag(0, 0, f[0]);
@@ -124,9 +128,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(GemmArgs g) {
     int cur = 0;                      // stage holding tile s
     // The body is branch-free: past the end it re-loads zeros (kofs >= k), stores them into a stage nobody reads again and
     // prefetches fragments that are never multiplied, which keeps the compiler's waitcnt bookkeeping exact.
-    for (int s = 0; s < nks; ++s) {
+    // step s: issue the loads of tile s+3 into `nxt_set`, multiply tile s, store tile s+2 (loaded during step s-1, `cur_set`) into
+    // the stage of tile s-1 (dead since the previous barrier).
+    auto step = [&](int sidx, const Raw& cur_set, Raw& nxt_set) {
         const int nxt = cur == 2 ? 0 : cur + 1, nx2 = nxt == 2 ? 0 : nxt + 1;
-        load_tile((s + 2) * KB);
+        load_tile((sidx + 3) * KB, nxt_set);
 #pragma unroll
         for (int kh = 0; kh < C::NKH; ++kh) {
             if (kh + 1 < C::NKH) read_frag(cur, kh + 1, f[(kh + 1) & 1]);
@@ -135,9 +141,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(GemmArgs g) {
             mma(f[kh & 1]);
             __builtin_amdgcn_sched_barrier(0);
         }
-        store_tile(nx2);                            // stage of tile s-1: its last reads finished before the previous barrier
+        store_tile(nx2, cur_set);
         __syncthreads();
         cur = nxt;
+    };
+    for (int s = 0; s < nks; s += 2) {
+        step(s, R0, R1);
+        if (s + 1 < nks) step(s + 1, R1, R0);
     }
 
     // ---- epilogue: lane holds column li of each 32-wide tile, rows (r&3) + 8*(r>>2) + 4*lh
@@ -178,26 +188,25 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmArgs g) {
     const int q4 = (tid & 31) * 4;
     const bool ak_ok = k0 + q4 < g.k, bn_ok = n0 + q4 < g.n;
     const int acol = ak_ok ? k0 + q4 : 0, bcol = bn_ok ? n0 + q4 : 0;
-    f32x4 ra[2], rb[2];
-    bool okt[2];
-    auto load_tile = [&](int t0) {
+    struct Raw { f32x4 ra[2], rb[2]; bool okt[2]; };      // two sets: loads issued two steps ahead of their LDS store (see gemm_nn_kernel)
+    auto load_tile = [&](int t0, Raw& R) {
 #pragma unroll
         for (int v = 0; v < 2; ++v) {
             const int t = t0 + (tid >> 5) + 8 * v;
-            okt[v] = t < t_end;
-            const long tr = okt[v] ? t : 0;
-            ra[v] = *reinterpret_cast<const f32x4*>(A + tr * g.lda + acol);
-            rb[v] = *reinterpret_cast<const f32x4*>(B + tr * g.ldb + bcol);
+            R.okt[v] = t < t_end;
+            const long tr = R.okt[v] ? t : 0;
+            R.ra[v] = *reinterpret_cast<const f32x4*>(A + tr * g.lda + acol);
+            R.rb[v] = *reinterpret_cast<const f32x4*>(B + tr * g.ldb + bcol);
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf, const Raw& R) {
         float* As = smem + buf * TN_STAGE;
         float* Bs = As + BK * TN_LD;
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int v = 0; v < 2; ++v) {
-            *reinterpret_cast<f32x4*>(As + ((tid >> 5) + 8 * v) * TN_LD + q4) = (okt[v] && ak_ok) ? ra[v] : zero;
-            *reinterpret_cast<f32x4*>(Bs + ((tid >> 5) + 8 * v) * TN_LD + q4) = (okt[v] && bn_ok) ? rb[v] : zero;
+            *reinterpret_cast<f32x4*>(As + ((tid >> 5) + 8 * v) * TN_LD + q4) = (R.okt[v] && ak_ok) ? R.ra[v] : zero;
+            *reinterpret_cast<f32x4*>(Bs + ((tid >> 5) + 8 * v) * TN_LD + q4) = (R.okt[v] && bn_ok) ? R.rb[v] : zero;
         }
     };
 
@@ -232,18 +241,20 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmArgs g) {
     };
 
     const int nks = (t_end - t_begin + BK - 1) / BK;
-    load_tile(t_begin);
-    store_tile(0);
-    load_tile(t_begin + BK);
-    store_tile(1);
+    Raw R0, R1;
+    load_tile(t_begin, R0);
+    load_tile(t_begin + BK, R1);
+    store_tile(0, R0);
+    store_tile(1, R1);
+    load_tile(t_begin + 2 * BK, R0);
     __syncthreads();
     Frag f0, f1;
     read_frag(0, 0, f0);
     __builtin_amdgcn_s_waitcnt(0xc07f);     // lgkmcnt(0), see gemm_nn_kernel
     int cur = 0;
-    for (int s = 0; s < nks; ++s) {          // branch-free body, see gemm_nn_kernel
+    auto step = [&](int sidx, const Raw& cur_set, Raw& nxt_set) {          // branch-free body, see gemm_nn_kernel
         const int nxt = cur == 2 ? 0 : cur + 1, nx2 = nxt == 2 ? 0 : nxt + 1;
-        load_tile(t_begin + (s + 2) * BK);
+        load_tile(t_begin + (sidx + 3) * BK, nxt_set);
         read_frag(cur, 1, f1);
         __builtin_amdgcn_sched_barrier(0);
         mma(f0);
@@ -252,9 +263,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmArgs g) {
         __builtin_amdgcn_sched_barrier(0);
         mma(f1);
         __builtin_amdgcn_sched_barrier(0);
-        store_tile(nx2);
+        store_tile(nx2, cur_set);
         __syncthreads();
         cur = nxt;
+    };
+    for (int s = 0; s < nks; s += 2) {
+        step(s, R0, R1);
+        if (s + 1 < nks) step(s + 1, R1, R0);
     }
 
     float* C = g.c + ((long)blockIdx.z * gridDim.y + z) * g.k * g.n;
