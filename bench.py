@@ -197,6 +197,9 @@ def main():
                                "kernel": roof["kernel"], "launches_per_step": roof["launches"] // args.steps,
                                "avg_launch_us": round(roof["avg_us"], 2), "share_of_step": round(roof["time_s"] / dt, 3),
                                "by_kernel": roof["by_kernel"]}
+            out["roofline"]["concurrency"] = ("weight-gradient kernels run on a second HIP stream during backward: launch durations (live events and rocprofv3 "
+                                              "alike) include time shared with them, so per-kernel rates read lower than standalone (tools/bench_conv.py, "
+                                              "tools/bench_gemm.py) while the step is faster (RUNET_NO_WGRAD_STREAM=1: 393 img/s, all rates standalone)")
             if roof["kernel"].startswith("gemm_"):
                 out["roofline"]["note"] = ("position-GEMMs of the unfused Winograd F(4x4,3x3) path (deep 3x3 convolutions): achieved = the GEMM's own "
                                            "2*36*tiles*K*N FLOPs / its launch time; the convolution it implements is 4x that in direct-conv FLOPs")

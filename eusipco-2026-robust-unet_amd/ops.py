@@ -182,7 +182,8 @@ class wgrad_side_stream:
     leaving the block makes the current stream wait for it.  ops.side_stream() is the active stream (the all-reduce must wait for it too)."""
 
     def __enter__(self):
-        if USE_WGRAD_STREAM and torch.cuda.is_available():        # under hipGraph capture the fork / join is captured with everything else
+        # not under hipGraph capture: a captured fork/join replays correctly but slowly (23 ms instead of 12 ms at 2x256x256 with 8 hardware queues)
+        if USE_WGRAD_STREAM and torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
             dev = torch.cuda.current_device()
             if ("s", dev) not in _side:
                 _side[("s", dev)] = torch.cuda.Stream(device=dev)
