@@ -292,16 +292,8 @@ int runet_gemm_nn_launch(const float* a, int lda, long sa, const float* b, long 
                          hipStream_t st) {
     GemmArgs g{};
     g.a = a; g.lda = lda; g.sa = sa; g.b = b; g.ldb = n; g.sb = sb; g.c = c; g.ldc = ldc; g.sc = sc; g.rows = rows; g.k = k; g.n = n;
-    static const int kb = getenv("RUNET_GEMM_KB") ? atoi(getenv("RUNET_GEMM_KB")) : 16;      // A/B switch for tools/bench_gemm.py
-    const dim3 grid(cdiv(rows, 128), cdiv(n, 128), batch);
-    if (kb == 32 && k % 32 == 0) {
-        static const bool ok = hipFuncSetAttribute((const void*)gemm_nn_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                   3 * NNCfg<32>::STAGE * (int)sizeof(float)) == hipSuccess;
-        if (!ok) return 1;
-        hipLaunchKernelGGL(gemm_nn_kernel<32>, grid, dim3(256), 3 * NNCfg<32>::STAGE * sizeof(float), st, g);
-    } else {
-        hipLaunchKernelGGL(gemm_nn_kernel<16>, grid, dim3(256), 3 * NNCfg<16>::STAGE * sizeof(float), st, g);
-    }
+    // 16-deep k-steps; the 32-deep instantiation (three 35 KB stages -> one block per CU) measured 5-10 % slower (tools/bench_gemm.py)
+    hipLaunchKernelGGL(gemm_nn_kernel<16>, dim3(cdiv(rows, 128), cdiv(n, 128), batch), dim3(256), 3 * NNCfg<16>::STAGE * sizeof(float), st, g);
     return 0;
 }
 
