@@ -144,3 +144,51 @@ def test_reference_style_loop_with_stock_loss_and_optimizer(pkg):
     pkg.bce_loss(b(x), y).backward()
     g2 = b.inc.conv2.weight.grad
     assert not torch.equal(g1, g2) and float(g2.abs().sum()) > float(g1.abs().sum())
+
+
+@pytest.mark.parametrize("n,h,w,base", [(2, 48, 80, 16), (2, 16, 16, 16), (3, 32, 96, 32)])
+def test_rectangular_and_minimum_sizes_against_the_oracle(pkg, oracle, n, h, w, base):
+    """H != W, odd deep-level sizes (48x80 -> 3x5 bottleneck: neither Winograd form applies there, the 24x40 / 12x20 / 6x10 levels mix
+    F(4x4), F(2x2) and direct kernels) and the smallest legal tile (16x16 -> 1x1 bottleneck): train step against the CPU oracle."""
+    dev = torch.device("cuda:0")
+    seed = 100 + h + w
+    model = pkg.RobustUNet(3, 1, base)
+    model.load_state_dict(oracle.init_state(3, 1, base, seed=seed, perturb_bn=True))
+    model = model.to(dev).train()
+    masks = oracle.dropout_masks(n, base, seed=seed)
+    model.set_dropout_masks({k: v.to(dev) for k, v in masks.items()})
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, 3, h, w, generator=g)
+    y = (torch.rand(n, 1, h, w, generator=g) > 0.5).float()
+    prob, logit = model(x.to(dev), return_logits=True)
+    loss = pkg.bce_loss(prob, y.to(dev))
+    loss.backward()
+    P = oracle.init_state(3, 1, base, seed=seed, perturb_bn=True)
+    names = oracle.param_names(3, 1, base)
+    for k in names:
+        P[k].requires_grad_(True)
+    rp, rl = oracle.forward(P, x, True, masks)
+    rloss = oracle.bce_mean(rp, y)
+    rloss.backward()
+    np.testing.assert_allclose(prob.detach().cpu().numpy(), rp.detach().numpy(), rtol=0, atol=1e-3)
+    lg = rl.detach().numpy()
+    np.testing.assert_allclose(logit.detach().cpu().numpy(), lg, rtol=1e-3, atol=1e-3 * max(1.0, float(np.abs(lg).max()) / 10))
+    assert abs(float(loss.detach()) - float(rloss.detach())) <= 1e-3 * max(1.0, abs(float(rloss.detach())))
+    gn = np.array([p.grad.double().norm().item() for p in model.parameters()])
+    rn = np.array([P[k].grad.double().norm().item() for k in names])
+    rel = np.abs(gn - rn) / (rn + 1e-3 * rn.max())
+    assert rel.max() < 3e-2, (names[int(rel.argmax())], gn[int(rel.argmax())], rn[int(rel.argmax())])
+
+
+def test_single_value_per_channel_in_training_raises_like_torch(pkg):
+    """1 x 16 x 16 in train mode reaches the bottleneck BatchNorm with ONE value per channel: torch raises ("Expected more than 1 value
+    per channel when training"), so does the HIP path; eval mode works."""
+    dev = torch.device("cuda:0")
+    model = pkg.RobustUNet(3, 1, 16).to(dev)
+    x = torch.zeros(1, 3, 16, 16, device=dev)
+    model.train()
+    with pytest.raises(RuntimeError):
+        model(x)
+    model.eval()
+    with torch.no_grad():
+        assert model(x).shape == (1, 1, 16, 16)
