@@ -163,6 +163,18 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     roof = None if prof is None else ops.stop_conv_profile(prof)
+    alone = None
+    if roof is not None and ops.USE_WGRAD_STREAM:
+        # outside the timed region: three more steps with the weight gradients back on the main stream, so that the dominant kernel's
+        # rate can also be quoted without a concurrent kernel sharing the GPU with it
+        ops.USE_WGRAD_STREAM = False
+        step(x, y)
+        p2 = ops.start_conv_profile()
+        for _ in range(3):
+            step(x, y)
+        torch.cuda.synchronize()
+        alone = ops.stop_conv_profile(p2)["by_kernel"].get(roof["kernel"])
+        ops.USE_WGRAD_STREAM = True
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -200,6 +212,9 @@ def main():
             out["roofline"]["concurrency"] = ("weight-gradient kernels run on a second HIP stream during backward: launch durations (live events and rocprofv3 "
                                               "alike) include time shared with them, so per-kernel rates read lower than standalone (tools/bench_conv.py, "
                                               "tools/bench_gemm.py) while the step is faster (RUNET_NO_WGRAD_STREAM=1: 393 img/s, all rates standalone)")
+            if alone is not None:      # [launches, total ms, TFLOP/s] of the same kernel in three single-stream steps after the timed region
+                out["roofline"]["standalone"] = {"achieved": alone[2], "frac": round(alone[2] / FP32_MFMA_PEAK_TFLOPS, 4),
+                                                 "avg_launch_us": round(1e3 * alone[1] / alone[0], 2)}
             if roof["kernel"].startswith("gemm_"):
                 out["roofline"]["note"] = ("position-GEMMs of the unfused Winograd F(4x4,3x3) path (deep 3x3 convolutions): achieved = the GEMM's own "
                                            "2*36*tiles*K*N FLOPs / its launch time; the convolution it implements is 4x that in direct-conv FLOPs")
