@@ -136,22 +136,26 @@ def bn_apply(x, scale, shift, mask=None, relu=False, out=None):
     return out
 
 
-def bn_backward(dy, x, mean, invstd, scale, sums, act=None, mask=None, out=None, sync=None):
-    """sums: [2c] destination for (dgamma | dbeta), always the LOCAL sums.  act/mask: fused relu(+dropout) backward.
+def bn_backward(dy, x, mean, invstd, scale, sums, act=None, mask=None, out=None, sync=None, relu_shift=None):
+    """sums: [2c] destination for (dgamma | dbeta), always the LOCAL sums.  act/mask: fused relu(+dropout) backward from the saved
+    activation; relu_shift (the forward's shift vector, with `scale` the forward's scale): the same from x alone, act is not read.
     sync (SyncBN): dx uses the all-reduced sums and the global element count.  -> dx"""
     n, h, w, c = x.shape
     hw = h * w
     st = ops.stream()
     ws = _ws(n, hw, c, x.device)
+    if relu_shift is not None:
+        act = None
     actp, lda = (act.data_ptr(), ops.ld(act)) if act is not None else (None, 0)
     maskp = mask.data_ptr() if mask is not None else None
+    rsc, rsh = (scale.data_ptr(), relu_shift.data_ptr()) if relu_shift is not None else (None, None)
     check(lib.runet_bn_bwd_reduce(dy.data_ptr(), ops.ld(dy), x.data_ptr(), ops.ld(x), actp, lda, n, hw, c, mean.data_ptr(), invstd.data_ptr(),
-                                  maskp, ws.data_ptr(), sums.data_ptr(), st))
+                                  maskp, ws.data_ptr(), sums.data_ptr(), rsc, rsh, st))
     if out is None:
         out = ops.empty_nhwc(n, h, w, c, x)
     use, m_total = (sums, 0) if sync is None else sync.reduce_sums(sums, n * hw)
     check(lib.runet_bn_bwd_apply(dy.data_ptr(), ops.ld(dy), x.data_ptr(), ops.ld(x), actp, lda, out.data_ptr(), ops.ld(out), n * hw, hw, c,
-                                 mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), use.data_ptr(), maskp, m_total, st))
+                                 mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), use.data_ptr(), maskp, m_total, rsh, st))
     return out
 
 
@@ -210,7 +214,7 @@ def rb_forward(x, p: RBParams, training, mask=None, save=True, stats_hook=None):
                            ops.ld(out), P, hw, c, st))
     if not save:
         return out, None
-    ctx = dict(x=x, r=r, t1=t1, a1=a1, t2=t2, out=out, mask=use_mask, p=p, sync=stats_hook if training else None, s1=s1, mean1=mean1, invstd1=invstd1, s2=s2, h2=h2,
+    ctx = dict(x=x, r=r, t1=t1, a1=a1, t2=t2, out=out, mask=use_mask, p=p, sync=stats_hook if training else None, s1=s1, h1=h1, mean1=mean1, invstd1=invstd1, s2=s2, h2=h2,
                mean2=mean2, invstd2=invstd2, ss=ss, mean_s=mean_s, invstd_s=invstd_s, A=A, B=B, ca=ca, avg=avg, mx=mx, idx=idx,
                tval=tval, mean_nc=mean_nc, smap=smap, amax=amax, sa=sa, v1=kv1.get("V"), v2=kv2.get("V"))
     return out, ctx
@@ -259,7 +263,7 @@ def rb_backward(ctx, dout, sink, pre="", need_dx=True):
     da1 = ops.conv_dgrad(dt2, p.w2)
     del dt2
     sums1 = sink.buf(pre, [("bn1.weight", (c,)), ("bn1.bias", (c,))])
-    dt1 = bn_backward(da1, t1, ctx["mean1"], ctx["invstd1"], ctx["s1"], sums1, act=a1, mask=ctx["mask"], out=da1, sync=sync)
+    dt1 = bn_backward(da1, t1, ctx["mean1"], ctx["invstd1"], ctx["s1"], sums1, mask=ctx["mask"], out=da1, sync=sync, relu_shift=ctx["h1"])
     ops.conv_wgrad(x, dt1, 3, 3, cin_w=p.cin_w, out=sink.buf(pre, [("conv1.weight", (3, 3, p.cin_w, c))]), v=ctx.get("v1"))
     ctx["v1"] = None
     dx = None
@@ -298,7 +302,7 @@ def dilated_forward(x, p: DilParams, training, save=True, stats_hook=None):
     out = bn_apply(cat, s, hsh, None, relu=True)
     if not save:
         return out, None
-    return out, dict(x=x, cat=cat, out=out, p=p, s=s, mean=mean, invstd=invstd, sync=stats_hook if training else None)
+    return out, dict(x=x, cat=cat, out=out, p=p, s=s, h=hsh, mean=mean, invstd=invstd, sync=stats_hook if training else None)
 
 
 def dilated_backward(ctx, dout, sink, pre="", need_dx=True):
@@ -311,7 +315,7 @@ def dilated_backward(ctx, dout, sink, pre="", need_dx=True):
     wb = [sink.buf(pre, [(f"conv{i + 1}.weight", (1 if i == 0 else 3, 1 if i == 0 else 3, cin, q)), (f"conv{i + 1}.bias", (q,))])
           for i in range(4)]
     sums = sink.buf(pre, [("bn.weight", (c,)), ("bn.bias", (c,))])
-    dcat = bn_backward(dout, cat, ctx["mean"], ctx["invstd"], ctx["s"], sums, act=out, mask=None, sync=ctx["sync"])
+    dcat = bn_backward(dout, cat, ctx["mean"], ctx["invstd"], ctx["s"], sums, mask=None, sync=ctx["sync"], relu_shift=ctx["h"])
     dx = None
     for i in range(4):
         sl = dcat[..., i * q:(i + 1) * q]

@@ -239,13 +239,17 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_partial(const float* __rest
                                                              int ldx, const float* __restrict__ act, int ldact, int HW, int C,
                                                              const float* __restrict__ mean, const float* __restrict__ invstd,
                                                              const float* __restrict__ mask, int pix_per_chunk,
-                                                             float* __restrict__ part) {
+                                                             float* __restrict__ part, const float* __restrict__ rscale,
+                                                             const float* __restrict__ rshift) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int cvec = C / VEC, rows = TPB / cvec, tid = threadIdx.x;
     const int col = tid % cvec, row = tid / cvec;
     const int n = blockIdx.y, chunk = blockIdx.x;
     const int p0 = chunk * pix_per_chunk, p1 = min(HW, p0 + pix_per_chunk);
-    float sg[VEC], sgx[VEC], mu[VEC], is[VEC], mk[VEC];
+    // ReLU(+Dropout2d) backward: either from the saved activation (act > 0) or, when rscale/rshift are given, recomputed from x with
+    // the forward's own expression x*scale + shift > 0 - one tensor less to read
+    const bool recompute = rscale != nullptr;
+    float sg[VEC], sgx[VEC], mu[VEC], is[VEC], mk[VEC], fs[VEC], fh[VEC];
 #pragma unroll
     for (int q = 0; q < VEC; ++q) {
         sg[q] = 0.f; sgx[q] = 0.f;
@@ -253,6 +257,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_partial(const float* __rest
         const bool ok = row < rows;
         mu[q] = ok ? mean[c] : 0.f; is[q] = ok ? invstd[c] : 0.f;
         mk[q] = (ok && mask) ? mask[(long)n * C + c] : 1.f;
+        fs[q] = (ok && recompute) ? rscale[c] : 0.f; fh[q] = (ok && recompute) ? rshift[c] : 0.f;
     }
     if (row < rows) {
         const long ib = (long)n * HW;
@@ -275,6 +280,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_partial(const float* __rest
             for (int q = 0; q < VEC; ++q) {
                 float gg = g[q];
                 if (act) gg = (av[q] > 0.f) ? gg * mk[q] : 0.f;
+                else if (recompute) gg = (xv[q] * fs[q] + fh[q] > 0.f) ? gg * mk[q] : 0.f;
                 sg[q] += gg;
                 sgx[q] += gg * (xv[q] - mu[q]) * is[q];
             }
@@ -317,20 +323,23 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const float* __restri
                                                            int ldx, const float* __restrict__ act, int ldact, float* __restrict__ dx,
                                                            int lddx, int HW, int C, int pix_per_chunk, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ scale,
-                                                           const float* __restrict__ sums, const float* __restrict__ mask, float inv_m) {
+                                                           const float* __restrict__ sums, const float* __restrict__ mask, float inv_m,
+                                                           const float* __restrict__ rshift) {
     const int cvec = C / VEC, rows = TPB / cvec, tid = threadIdx.x;
     const int col = tid % cvec, row = tid / cvec;
     if (row >= rows) return;
     const int n = blockIdx.y;
     const int p0 = blockIdx.x * pix_per_chunk, p1 = min(HW, p0 + pix_per_chunk);
     // dx = sc*(g - k1 - xhat*k2) = g*sc + x*a + b  with a = -sc*k2*invstd, b = sc*(mean*invstd*k2 - k1)
-    float sc[VEC], ca[VEC], cb[VEC], mk[VEC];
+    const bool recompute = rshift != nullptr;        // ReLU mask from x*scale + shift > 0 (scale IS the forward scale) instead of act > 0
+    float sc[VEC], ca[VEC], cb[VEC], mk[VEC], fh[VEC];
 #pragma unroll
     for (int q = 0; q < VEC; ++q) {
         const int c = col * VEC + q;
         const float s = scale[c], k1 = sums[C + c] * inv_m, k2 = sums[c] * inv_m, is = invstd[c];
         sc[q] = s; ca[q] = -s * k2 * is; cb[q] = s * (mean[c] * is * k2 - k1);
         mk[q] = mask ? mask[(long)n * C + c] : 1.f;
+        fh[q] = recompute ? rshift[c] : 0.f;
     }
     const long ib = (long)n * HW;
     for (int p = p0 + row; p < p1; p += rows) {
@@ -353,6 +362,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const float* __restri
         for (int q = 0; q < VEC; ++q) {
             float gg = g[q];
             if (act) gg = (av[q] > 0.f) ? gg * mk[q] : 0.f;
+            else if (recompute) gg = (xv[q] * sc[q] + fh[q] > 0.f) ? gg * mk[q] : 0.f;
             r[q] = gg * sc[q] + xv[q] * ca[q] + cb[q];
         }
         if constexpr (VEC == 4) {
@@ -504,8 +514,9 @@ extern "C" int runet_bn_apply(const float* x, int ldx, float* y, int ldy, long p
 
 extern "C" int runet_bn_bwd_reduce(const float* dy, int lddy, const float* x, int ldx, const float* act, int ldact, int n_img,
                                    int hw, int c, const float* mean, const float* invstd, const float* mask_nc,
-                                   float* workspace, float* sums, void* stream) {
+                                   float* workspace, float* sums, const float* relu_scale, const float* relu_shift, void* stream) {
     RUNET_REQUIRE(dy && x && mean && invstd && workspace && sums, "null pointer");
+    RUNET_REQUIRE((relu_scale == nullptr) == (relu_shift == nullptr) && !(act && relu_scale), "give either act or relu_scale + relu_shift");
     REQ_VEC(c);
     hipStream_t st = (hipStream_t)stream;
     const int vec = (c % 4 == 0) ? 4 : 1, cvec = c / vec, rows = TPB / cvec;
@@ -513,8 +524,8 @@ extern "C" int runet_bn_bwd_reduce(const float* dy, int lddy, const float* x, in
     const int ppc = (hw + chunks - 1) / chunks;
     const size_t lds = (size_t)rows * c * 2 * sizeof(float);
     dim3 grid(chunks, n_img);
-    if (vec == 4) hipLaunchKernelGGL((bn_bwd_reduce_partial<4>), grid, dim3(TPB), lds, st, dy, lddy, x, ldx, act, ldact, hw, c, mean, invstd, mask_nc, ppc, workspace);
-    else hipLaunchKernelGGL((bn_bwd_reduce_partial<1>), grid, dim3(TPB), lds, st, dy, lddy, x, ldx, act, ldact, hw, c, mean, invstd, mask_nc, ppc, workspace);
+    if (vec == 4) hipLaunchKernelGGL((bn_bwd_reduce_partial<4>), grid, dim3(TPB), lds, st, dy, lddy, x, ldx, act, ldact, hw, c, mean, invstd, mask_nc, ppc, workspace, relu_scale, relu_shift);
+    else hipLaunchKernelGGL((bn_bwd_reduce_partial<1>), grid, dim3(TPB), lds, st, dy, lddy, x, ldx, act, ldact, hw, c, mean, invstd, mask_nc, ppc, workspace, relu_scale, relu_shift);
     const int cw = final_cw(c, (long)chunks * n_img);
     hipLaunchKernelGGL(bn_bwd_reduce_final, dim3(cdiv(c, cw)), dim3(TPB), 0, st, workspace, chunks * n_img, c, cw, sums);
     RUNET_CHECK_LAUNCH();
@@ -522,8 +533,9 @@ extern "C" int runet_bn_bwd_reduce(const float* dy, int lddy, const float* x, in
 
 extern "C" int runet_bn_bwd_apply(const float* dy, int lddy, const float* x, int ldx, const float* act, int ldact, float* dx,
                                   int lddx, long pixels, int hw, int c, const float* mean, const float* invstd,
-                                  const float* scale, const float* sums, const float* mask_nc, long m_total, void* stream) {
-    RUNET_REQUIRE(dy && x && dx && mean && invstd && scale && sums, "null pointer");
+                                  const float* scale, const float* sums, const float* mask_nc, long m_total, const float* relu_shift,
+                                  void* stream) {
+    RUNET_REQUIRE(dy && x && dx && mean && invstd && scale && sums && !(act && relu_shift), "null pointer / both act and relu_shift");
     REQ_VEC(c);
     hipStream_t st = (hipStream_t)stream;
     const float inv_m = 1.0f / (float)(m_total > 0 ? m_total : pixels);
@@ -531,8 +543,8 @@ extern "C" int runet_bn_bwd_apply(const float* dy, int lddy, const float* x, int
     const int nimg = (int)(pixels / hw), vec = (c % 4 == 0) ? 4 : 1;
     int ppc;
     const int chunks = stream_chunks(nimg, hw, c, TPB / (c / vec), ppc);
-    if (vec == 4) hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3(chunks, nimg), dim3(TPB), 0, st, dy, lddy, x, ldx, act, ldact, dx, lddx, hw, c, ppc, mean, invstd, scale, sums, mask_nc, inv_m);
-    else hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3(chunks, nimg), dim3(TPB), 0, st, dy, lddy, x, ldx, act, ldact, dx, lddx, hw, c, ppc, mean, invstd, scale, sums, mask_nc, inv_m);
+    if (vec == 4) hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3(chunks, nimg), dim3(TPB), 0, st, dy, lddy, x, ldx, act, ldact, dx, lddx, hw, c, ppc, mean, invstd, scale, sums, mask_nc, inv_m, relu_shift);
+    else hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3(chunks, nimg), dim3(TPB), 0, st, dy, lddy, x, ldx, act, ldact, dx, lddx, hw, c, ppc, mean, invstd, scale, sums, mask_nc, inv_m, relu_shift);
     RUNET_CHECK_LAUNCH();
 }
 

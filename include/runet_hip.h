@@ -89,14 +89,17 @@ int runet_bn_finalize(const float* mean_nc, const float* m2_nc, int n_img, int c
 int runet_bn_apply(const float* x, int ldx, float* y, int ldy, long pixels, int hw, int c, const float* scale, const float* shift,
                    const float* mask_nc, int relu, void* stream);
 
-/* g = dy, or dy*mask_nc[n,c]*(act > 0) when act != NULL (act = saved output of relu/dropout).
+/* g = dy, or dy*mask_nc[n,c]*(act > 0) when act != NULL (act = saved output of relu/dropout), or - relu_scale/relu_shift given, act NULL -
+ * dy*mask_nc[n,c]*(x*relu_scale[c] + relu_shift[c] > 0): the forward's affine recomputed from x, one tensor less to read.
  * sums[0:c] = sum g*xhat (= dgamma), sums[c:2c] = sum g (= dbeta): the order of (weight, bias). */
 int runet_bn_bwd_reduce(const float* dy, int lddy, const float* x, int ldx, const float* act, int ldact, int n_img, int hw, int c,
-                        const float* mean, const float* invstd, const float* mask_nc, float* workspace, float* sums, void* stream);
-/* dx = scale*(g - sums[C+c]/M - xhat*sums[c]/M), M = m_total if > 0 else pixels (SyncBN: sums all-reduced, M = global count) */
+                        const float* mean, const float* invstd, const float* mask_nc, float* workspace, float* sums, const float* relu_scale,
+                        const float* relu_shift, void* stream);
+/* dx = scale*(g - sums[C+c]/M - xhat*sums[c]/M), M = m_total if > 0 else pixels (SyncBN: sums all-reduced, M = global count);
+ * relu_shift (act NULL): g as above with relu_scale = scale */
 int runet_bn_bwd_apply(const float* dy, int lddy, const float* x, int ldx, const float* act, int ldact, float* dx, int lddx,
                        long pixels, int hw, int c, const float* mean, const float* invstd, const float* scale, const float* sums,
-                       const float* mask_nc, long m_total, void* stream);
+                       const float* mask_nc, long m_total, const float* relu_shift, void* stream);
 /* out[c] (=|+=) sum over pixels of x[p, c]  (bias gradients) */
 int runet_chan_sum(const float* x, int ld, long pixels, int c, float* workspace, float* out, int accumulate, void* stream);
 
