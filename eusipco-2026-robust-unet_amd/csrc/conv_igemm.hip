@@ -1039,6 +1039,14 @@ extern "C" int runet_gemm_batched(const float* a, int lda, long stride_a, const 
     g.Hout = 1; g.Wout = rows; g.o_scale = 1; g.zbatch = 1; g.zs_x = stride_a; g.zs_w = stride_b; g.zs_y = stride_c;
     hipStream_t st = (hipStream_t)stream;
     static const bool old_path = getenv("RUNET_GEMM_OLD") != nullptr;      // A/B switch for tools/bench_gemm.py
+    {   // 128x64 tiles where 128x128 tiles would fill the 256 CUs unevenly (e.g. 576 blocks = 2.25 per CU -> 3 rounds for 2.25 of work)
+        const long b128 = (long)cdiv(rows, 128) * cdiv(n, 128) * batch;
+        const double per_cu = b128 / 256.0, bal = per_cu / (double)((b128 + 255) / 256);
+        if (!old_path && bal < 0.8 && n % 64 == 0) {
+            launch_igemm<128, 64, 64, 32, false>(g, batch, st);
+            RUNET_CHECK_LAUNCH();
+        }
+    }
     if (!old_path && n >= 96) {
         runet_gemm_nn_launch(a, lda, stride_a, b, stride_b, c, ldc, stride_c, batch, rows, k, n, st);
         RUNET_CHECK_LAUNCH();
