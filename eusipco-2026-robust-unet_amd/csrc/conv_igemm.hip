@@ -1027,6 +1027,19 @@ extern "C" int runet_conv_wgrad_general(const float* x, int ldx, const float* dy
 // Batched plain GEMMs on the same kernels (the 36 position-GEMMs of the unfused Winograd F(4x4,3x3) path, conv_winograd4.hip).
 //   runet_gemm_batched   : C[z][rows][n] = A[z][rows][k] . B[z][k][n]                (blockIdx.z = z)
 //   runet_gemm_tn_batched: C[split][z][k][n] = sum over the split's rows of A[z][row][k] * B[z][row][n];  splits = ceil(rows / rows_per_split)
+// which device kernel runet_gemm_batched launches for a shape (live profiling labels must match the rocprofv3 kernel names)
+extern "C" const char* runet_gemm_batched_kernel_name(int batch, int rows, int k, int n) {
+    static const bool old_path = getenv("RUNET_GEMM_OLD") != nullptr;
+    const long b128 = (long)cdiv(rows, 128) * cdiv(n, 128) * batch;
+    const double per_cu = b128 / 256.0, bal = per_cu / (double)((b128 + 255) / 256);
+    if (!old_path && bal < 0.8 && n % 64 == 0) return "igemm_kernel<128, 64, 64, 32, false>";
+    if (!old_path && n >= 96) return "gemm_nn_kernel<16>";
+    if (n % 128 == 0 && b128 >= 256) return "igemm_kernel<128, 128, 64, 64, false>";
+    if (n > 32 && (long)cdiv(rows, 128) * cdiv(n, 64) * batch >= 256) return "igemm_kernel<128, 64, 64, 32, false>";
+    if (n > 32) return "igemm_kernel<64, 64, 32, 32, false>";
+    return "igemm_kernel<128, 32, 32, 32, false>";
+}
+
 extern "C" int runet_gemm_batched(const float* a, int lda, long stride_a, const float* b, long stride_b, float* c, int ldc, long stride_c,
                                   int batch, int rows, int k, int n, void* stream) {
     RUNET_REQUIRE(a && b && c && batch > 0 && batch <= 65535 && rows > 0, "bad arguments");

@@ -457,7 +457,7 @@ def wino4_conv(x, U, bias=None, out=None, accumulate=False, keep_v=None):
     check(lib.runet_gemm_batched(V, k, t * k, U.data_ptr(), k * nn_, M, nn_, t * nn_, 36, t, k, nn_, stream()))
     if _PROFILE is not None:
         e1.record()
-        _PROFILE.append(("gemm_nn_kernel", 2.0 * 36 * t * k * nn_, e0, e1))
+        _PROFILE.append((lib.runet_gemm_batched_kernel_name(36, t, k, nn_).decode(), 2.0 * 36 * t * k * nn_, e0, e1))
     check(lib.runet_wino4_output(M, nn_, n, h, w, bp, out.data_ptr(), ld(out), int(accumulate), stream()))
     return out
 

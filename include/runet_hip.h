@@ -179,6 +179,9 @@ int runet_gemm_batched(const float* a, int lda, long stride_a, const float* b, l
                        int k, int n, void* stream);
 int runet_gemm_tn_batched(const float* a, int lda, long stride_a, const float* b, int ldb, long stride_b, float* c, int batch, int rows, int k, int n,
                           int rows_per_split, void* stream);
+/* name of the device kernel runet_gemm_batched launches for this shape (128x128 LDS-ring kernel, or 128x64 tiles where those would
+ * fill the 256 CUs unevenly) - for matching live timings with rocprofv3 rows */
+const char* runet_gemm_batched_kernel_name(int batch, int rows, int k, int n);
 
 /* ---- Winograd F(4x4,3x3), unfused, for the deep 3x3 convolutions (Main_Final.py:157,159 at >= 256 channels) and their autograd ----
  * U [36][K][N] from runet_wino4_weights (dgrad != 0: rotated filter, K = cout, N = cin).  conv: x [n,h,w,K] -> y [n,h,w,N] ('same'), H, W % 4 == 0.
