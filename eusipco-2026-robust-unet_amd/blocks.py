@@ -264,7 +264,9 @@ def rb_backward(ctx, dout, sink, pre="", need_dx=True):
     del dt2
     sums1 = sink.buf(pre, [("bn1.weight", (c,)), ("bn1.bias", (c,))])
     dt1 = bn_backward(da1, t1, ctx["mean1"], ctx["invstd1"], ctx["s1"], sums1, mask=ctx["mask"], out=da1, sync=sync, relu_shift=ctx["h1"])
-    ops.conv_wgrad(x, dt1, 3, 3, cin_w=p.cin_w, out=sink.buf(pre, [("conv1.weight", (3, 3, p.cin_w, c))]), v=ctx.get("v1"))
+    # the first block of the network (need_dx False) ends the backward chain: nothing is left on the main stream to overlap with, so its
+    # last weight gradient runs there, next to the conv2 weight gradient still on the side stream
+    ops.conv_wgrad(x, dt1, 3, 3, cin_w=p.cin_w, out=sink.buf(pre, [("conv1.weight", (3, 3, p.cin_w, c))]), v=ctx.get("v1"), on_side=need_dx)
     ctx["v1"] = None
     dx = None
     if p.ws is not None:

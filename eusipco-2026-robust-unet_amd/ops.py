@@ -214,8 +214,8 @@ def _on_side(fn, tensors):
     return r
 
 
-def conv_wgrad(x, dy, kh, kw, cin_w=None, dil=1, out=None, v=None):
-    if _side.get("active") is not None:
+def conv_wgrad(x, dy, kh, kw, cin_w=None, dil=1, out=None, v=None, on_side=True):
+    if on_side and _side.get("active") is not None:
         if out is None:
             out = torch.empty((kh, kw, x.shape[3] if cin_w is None else cin_w, dy.shape[3]), device=x.device, dtype=torch.float32)
         return _on_side(lambda: _conv_wgrad(x, dy, kh, kw, cin_w, dil, out, v), (x, dy, out, v))
