@@ -30,6 +30,31 @@ __device__ __forceinline__ float grp_sum16(float v) {
 }
 
 // --------------------------------------------------------------------------------- channel attention
+// hid[0:Cr] = W0p^T avg, hid[Cr:2Cr] = W0p^T mx for one image.  Thread (j, part) walks rows c = part, part + P, ... of W0p[c][j]: lanes
+// with consecutive j (then consecutive rows) read consecutive addresses; the P partials are summed through LDS in a fixed order.  (One
+// wave per output with the lanes striding over c read 64 different cache lines per load: 25-45 us per launch at C = 1024.)
+__device__ __forceinline__ void ca_hidden(const float* __restrict__ W0p, const float* avg, const float* mxv, int C, int Cr, float* hid,
+                                          float* part /* [2 * TPB] */) {
+    const int tid = threadIdx.x;
+    const int P = TPB / Cr;
+    const int j = tid % Cr, pt = tid / Cr;
+    float pa = 0.f, pm = 0.f;
+    if (pt < P)
+        for (int c = pt; c < C; c += P) {
+            const float w = W0p[c * Cr + j];
+            pa += w * avg[c];
+            pm += w * mxv[c];
+        }
+    part[tid] = pa; part[TPB + tid] = pm;
+    __syncthreads();
+    for (int o = tid; o < 2 * Cr; o += TPB) {
+        const float* src = part + (o < Cr ? 0 : TPB) + (o % Cr);
+        float acc = 0.f;
+        for (int q = 0; q < P; ++q) acc += src[q * Cr];
+        hid[o] = acc;
+    }
+}
+
 // grid N, block 256.  W0p[c][j] (C x Cr), W2p[j][c] (Cr x C).
 __global__ __launch_bounds__(TPB) void ca_coeff_kernel(const float* __restrict__ mean_nc, const float* __restrict__ max_nc,
                                                        const float* __restrict__ min_nc, const int* __restrict__ imax_nc,
@@ -52,16 +77,7 @@ __global__ __launch_bounds__(TPB) void ca_coeff_kernel(const float* __restrict__
         if (avg_out) { avg_out[n * C + c] = avg[c]; mx_out[n * C + c] = mxv[c]; idx_out[n * C + c] = pos ? imax_nc[n * C + c] : imin_nc[n * C + c]; tval_out[n * C + c] = tv; }
     }
     __syncthreads();
-    // hidden: 2*Cr dot products of length C; one wave per output, strided
-    const int wid = tid >> 6, lane = tid & 63;
-    for (int o = wid; o < 2 * Cr; o += TPB / 64) {
-        const int j = o % Cr;
-        const float* v = (o < Cr) ? avg : mxv;
-        float acc = 0.f;
-        for (int c = lane; c < C; c += 64) acc += W0p[c * Cr + j] * v[c];
-        acc = wave_sum(acc);
-        if (lane == 0) hid[o] = acc;
-    }
+    ca_hidden(W0p, avg, mxv, C, Cr, hid, sm + 2 * C + 2 * Cr);
     __syncthreads();
     for (int c = tid; c < C; c += TPB) {
         float za = 0.f, zm = 0.f;
@@ -333,14 +349,7 @@ __global__ __launch_bounds__(TPB) void ca_bwd_image_kernel(const float* __restri
         dz[c] = dca * k * (1.f - k);
         dz_out[n * C + c] = dz[c];
     }
-    for (int o = wid; o < 2 * Cr; o += TPB / 64) {
-        const int j = o % Cr;
-        const float* v = (o < Cr) ? avg_n : mx_n;
-        float acc = 0.f;
-        for (int c = lane; c < C; c += 64) acc += W0p[c * Cr + j] * v[c];
-        acc = wave_sum(acc);
-        if (lane == 0) hid[o] = acc;
-    }
+    ca_hidden(W0p, avg_n, mx_n, C, Cr, hid, sm + C + 3 * Cr);
     __syncthreads();
     for (int j = wid; j < Cr; j += TPB / 64) {
         float acc = 0.f;
@@ -642,7 +651,7 @@ extern "C" int runet_ca_coeff(const float* mean_nc, const float* max_nc, const f
     REQ_C4(c);
     RUNET_REQUIRE(cr >= 1 && cr <= c, "bad hidden width");
     RUNET_REQUIRE(!avg || (mx && idx && tval), "save buffers must come together");
-    const size_t lds = (2 * c + 2 * cr) * sizeof(float);
+    const size_t lds = (2 * c + 2 * cr + 2 * TPB) * sizeof(float);
     hipLaunchKernelGGL(ca_coeff_kernel, dim3(n_img), dim3(TPB), lds, (hipStream_t)stream, mean_nc, max_nc, min_nc, imax_nc, imin_nc, s2, h2,
                        w0p, w2p, c, cr, A, B, ca, avg, mx, idx, tval);
     RUNET_CHECK_LAUNCH();
@@ -725,7 +734,7 @@ extern "C" int runet_ca_bwd(const float* sdu, const float* sdut, const float* s2
     hipStream_t st = (hipStream_t)stream;
     float* dz = workspace;                              // [n_img][c]
     float* hvec = workspace + (long)n_img * c;          // [n_img][3][cr]
-    const size_t lds = (c + 3 * cr) * sizeof(float);
+    const size_t lds = (c + 3 * cr + 2 * TPB) * sizeof(float);
     hipLaunchKernelGGL(ca_bwd_image_kernel, dim3(n_img), dim3(TPB), lds, st, sdu, sdut, s2, h2, ca, avg, mx, w0p, w2p, c, cr, davg, dmx, dz, hvec);
     const int tot = c * cr > c ? c * cr : c;
     hipLaunchKernelGGL(ca_bwd_final_kernel, dim3(cdiv(tot, 128)), dim3(128), 0, st, sdu, sdut, ca, davg, dmx, mean_nc, tval, mean2, invstd2, avg, mx,
