@@ -1,41 +1,59 @@
-#!/usr/bin/env python3
 """bench.py - training images/sec of the Robust U-Net hot path on N MI355X (one process per GPU).
 
-Workload (BASELINE.json metric / configs[1]): Robust U-Net (base 64, 40.9 M parameters), 256x256 RGB tiles,
-batch 16 PER GPU (weak scaling), fp32, synthetic data resident in HBM; one step = zero_grad + forward + BCE +
-backward (+ RCCL gradient all-reduce for N > 1, overlapped with backward) + fused Adam, Dropout2d and batch-stat
-BatchNorm on (train mode).  W untimed warm-up steps, then exactly K timed steps between barrier + device
-synchronisation; the maximum over ranks is reported by rank 0 as one JSON line.
+Workload (BASELINE.json metric / configs[1]): Robust U-Net (base 64, 40.9 M parameters), 256x256 RGB tiles, batch 16 PER GPU
+(weak scaling: the per-GPU work is fixed as N grows), fp32, synthetic data resident in HBM; one step = zero_grad + forward + BCE +
+backward (+ RCCL gradient all-reduce for N > 1, overlapped with backward) + fused Adam, Dropout2d and batch-stat BatchNorm on
+(train mode).  W untimed warm-up steps, then exactly K timed steps between barrier + device synchronisation; the maximum over
+ranks is reported by rank 0 as ONE JSON line.
 
-Extra objects on that line:
-  roofline     - the dominant convolution kernel (by total time: the fused Winograd F(2x2,3x3) kernel `wino_conv_kernel`,
-                 forward + data-gradient launches): ALGORITHMIC FLOPs per launch (the direct convolution's 2*9*Cin*Cout per
-                 pixel) / average launch duration measured with HIP events on the launch stream during
-                 the timed steps, against the 157.3 TFLOP/s dense fp32 matrix peak of gfx950.  Winograd executes 16/36 of
-                 those multiplies, so `frac` can exceed 1; `mfma_frac` is the matrix-pipe utilisation of the work actually
-                 executed.  `by_kernel` lists every convolution kernel family [launches, ms, algorithmic TFLOP/s].
-  cpu_baseline - the oracle (stock torch CPU ops, same train step) timed on this host's cores on a bounded sample
-                 (rank 0, N = 1 only).
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts its own N ranks: the parent (which never touches
+the GPU) runs `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same args>` as a
+child process and relays rank 0's line.  Launched under torch.distributed.run it is a rank.
+
+For N > 1 the line also carries `strong` (the BASELINE metric's global batch of 16 split over the ranks, per-rank BatchNorm) and
+`sync_bn` (the weak run with cross-rank BatchNorm statistics): SURVEY.md section 8(d).
+
+`--config K` selects one of BASELINE.json's five configurations (1: 2x64x64; 2: 16x256x256 - the default; 3: 4x512x512 per GPU in
+bf16; 4: DeepLabV3+ 16x256x256; 5: 1x1024x1024 per GPU, bf16 operands, hipGraph-captured step when single-process).
+
+Extra objects on the line:
+  roofline     - the dominant matrix-core kernel of the step (largest accumulated launch time).  `frac` = EXECUTED multiply-add FLOPs
+                 per launch / average launch duration / dense MFMA peak of the operand type (fp32 157.3 TFLOP/s; bf16 2500), the
+                 duration measured with HIP events on the launch stream inside the timed steps.  Winograd kernels execute 16/36
+                 (F(2x2)) or 36/144 (F(4x4)) of the direct convolution's multiplies: `algorithmic` is the direct-conv rate (SURVEY
+                 section 8d), `frac` the matrix-pipe utilisation of the work actually issued.  `step_mfma_frac` = executed FLOPs of
+                 ALL matrix-core launches of a step / step time / peak.  `traffic` = HBM bytes per launch of that kernel from the
+                 committed rocprofv3 PMC passes named in `traffic_source` (rocprofv3 cannot run inside bench.py); `hbm` = the
+                 whole step's PMC byte count from the same file.
+  cpu_baseline - the oracle (stock torch CPU ops, same train step, same batch) timed on this host's cores (rank 0, N = 1 only).
 """
 import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
+import sys
+import time
 
 # More hardware queues than HIP's default of 4: main, weight-gradient, communication and RCCL-internal streams otherwise share
 # queues and serialise on each other's event waits (measured with a single-rank process group: 380 img/s at the default, 414 with 8).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-import sys
-import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 PKG = "eusipco-2026-robust-unet_amd"
-FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}   # MI355X_MICROARCH.md: dense matrix peaks (v_mfma_f32_32x32x2_f32 / v_mfma_f32_32x32x16_bf16)
+TRAFFIC_FILE = {"f32": "profiles/round2_pmc_traffic.json", "bf16": "profiles/round2_pmc_traffic_bf16.json"}
+
+CONFIGS = {   # BASELINE.json `configs`, per-GPU shard
+    1: dict(model="runet", batch=2, size=64, dtype="f32"),
+    2: dict(model="runet", batch=16, size=256, dtype="f32"),
+    3: dict(model="runet", batch=4, size=512, dtype="bf16"),
+    4: dict(model="deeplab", batch=16, size=256, dtype="f32"),
+    5: dict(model="runet", batch=1, size=1024, dtype="bf16", graph=True),
+}
 
 
 def usable_cores():
@@ -54,13 +72,77 @@ def log(msg):
     print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
 
-def cpu_baseline(size, seed):
-    """Oracle train step on the host cores; bounded sample (about 10-30 s)."""
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", type=int, default=0, choices=[0, 1, 2, 3, 4, 5], help="BASELINE.json configuration (default: 2)")
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU")
+    ap.add_argument("--global-batch", type=int, default=0, help="strong scaling: this many images split across the ranks (overrides --batch)")
+    ap.add_argument("--size", type=int, default=None)
+    ap.add_argument("--base", type=int, default=64)
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default=None, help="operand type of the matrix-core kernels (accumulation, master weights, "
+                    "BatchNorm statistics and the optimizer stay fp32)")
+    ap.add_argument("--model", choices=["runet", "deeplab"], default=None)
+    ap.add_argument("--graph", action="store_true", help="hipGraph-captured step (single process only)")
+    ap.add_argument("--sync-bn", action="store_true", help="primary run with cross-rank BatchNorm statistics (results equal the global-batch step)")
+    ap.add_argument("--no-extra-runs", action="store_true", help="N > 1: skip the `strong` and `sync_bn` sub-runs")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--selftest-launch", action="store_true", help=argparse.SUPPRESS)   # CPU test of the self-launcher (gloo, no GPU)
+    args = ap.parse_args(argv)
+    cfg = CONFIGS[args.config or 2]
+    for k in ("model", "batch", "size", "dtype"):
+        if getattr(args, k) is None:
+            setattr(args, k, cfg[k])
+    if cfg.get("graph"):
+        args.graph = True
+    return args
+
+
+# ------------------------------------------------------------------------------------------------ self-launch (parent never touches the GPU)
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(nproc, argv):
+    """Run `nproc` ranks of this script as children (torch.distributed.run); relay their stderr and rank 0's JSON line.  -> exit code"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores() // nproc)))
+    log(f"starting {nproc} ranks: {' '.join(cmd[1:])}")
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for out in proc.stdout:
+        s = out.strip()
+        if s.startswith("{") and s.endswith("}"):
+            line = s
+        elif s:
+            print(s, file=sys.stderr, flush=True)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        rc = 1
+        log("no JSON line came back from rank 0")
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def cpu_baseline(batch, size, seed):
+    """Oracle train step on the host cores at the benchmarked batch, bounded to about 10-30 s after one warm-up step."""
+    import torch
     oracle = importlib.import_module("oracle.robust_unet_ref")
     data = importlib.import_module(PKG + ".data")
     cores = usable_cores()
     torch.set_num_threads(cores)
-    n = 4
+    # ~0.75 s per 256x256 image and step on 16 cores: keep warm-up + timed steps within the bound
+    n = batch if batch * (size / 256.0) ** 2 <= 16 else max(1, int(16 / (size / 256.0) ** 2))
     net = oracle.OracleNet(3, 1, 64, seed=seed).train()
     opt = torch.optim.Adam(net.parameters(), lr=1e-4, weight_decay=1e-4)
     x, y = data.synthetic_batch(n, size, seed=seed)
@@ -73,46 +155,50 @@ def cpu_baseline(size, seed):
         opt.step()
         return loss.item()
 
-    log(f"cpu_baseline: oracle on {cores} host threads, warm-up step ...")
-    step()                                   # warm-up
-    log("cpu_baseline: timing ...")
+    log(f"cpu_baseline: oracle on {cores} host threads, {n} images per step, warm-up step ...")
+    t0 = time.time()
+    step()
+    warm = time.time() - t0
+    log(f"cpu_baseline: warm-up {warm:.1f} s; timing ...")
     t0 = time.time()
     steps = 0
-    while steps < 2 or (time.time() - t0 < 10.0 and steps < 8):
+    while steps < 1 or (time.time() - t0 + warm < 20.0 and steps < 8):
         step()
         steps += 1
     dt = time.time() - t0
     return {"value": round(n * steps / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{steps} train steps of {n} images {size}x{size} (fwd+BCE+bwd+Adam, fp32, torch CPU ops) after 1 warm-up"}
+            "sample": f"{steps} train step(s) of {n} images {size}x{size} (fwd+BCE+bwd+Adam, fp32, torch CPU ops) after 1 warm-up step"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=16, help="images per GPU")
-    ap.add_argument("--global-batch", type=int, default=0, help="strong scaling: this many images split across the ranks (overrides --batch)")
-    ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--base", type=int, default=64)
-    ap.add_argument("--sync-bn", action="store_true", help="cross-rank BatchNorm statistics (results equal the global-batch step)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-roofline", action="store_true")
-    args = ap.parse_args()
+# ------------------------------------------------------------------------------------------------ one rank
+def selftest_rank():
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    t = torch.ones(1) * (dist.get_rank() + 1)
+    dist.all_reduce(t)
+    if dist.get_rank() == 0:
+        print(json.dumps({"selftest": True, "world": dist.get_world_size(), "sum": float(t.item())}), flush=True)
+    dist.destroy_process_group()
+
+
+def run_rank(args):
+    import torch
+    import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     strong = args.global_batch > 0
     if strong:
         if args.global_batch % world:
             raise SystemExit("--global-batch must be divisible by the number of ranks")
         args.batch = args.global_batch // world
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    # rehearsal knobs for a 1-GPU box (never used by the driver): all ranks on cuda:0, collectives over gloo
+    # rehearsal knob for a 1-GPU box (never used by the driver): all ranks on cuda:0, collectives over gloo
     one_device = os.environ.get("RUNET_BENCH_ONE_DEVICE") == "1"
-    backend = os.environ.get("RUNET_BENCH_BACKEND", "nccl")
+    backend = os.environ.get("RUNET_BENCH_BACKEND", "gloo" if one_device else "nccl")
     dev_index = 0 if one_device else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -127,20 +213,27 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+    comm = {"nccl": "RCCL", "gloo": "gloo (host-staged rehearsal, not RCCL)"}.get(backend, backend)
 
     pkg = importlib.import_module(PKG)
     ops = importlib.import_module(PKG + ".ops")
     torch.manual_seed(1234 + rank)             # dropout draws differ per rank
-    model = pkg.RobustUNet(3, 1, args.base).to(dev).train()
+    if args.model == "deeplab":
+        if use_dist:
+            raise SystemExit("the DeepLabV3+ baseline (config 4) is single-process")
+        model = pkg.DeepLabV3Plus(n_classes=1).to(dev).train()
+    else:
+        model = pkg.RobustUNet(3, 1, args.base).to(dev).train()
+    if args.dtype != "f32":
+        if not hasattr(model, "set_precision"):
+            raise SystemExit(f"--dtype {args.dtype} is not available for --model {args.model}")
+        model.set_precision(args.dtype)
     sync = None
     if use_dist:
-        sync = pkg.GradAllReducer(model, sync_bn=args.sync_bn)
+        sync = pkg.GradAllReducer(model, sync_bn=False)
         sync.broadcast_parameters(0)
-    if os.environ.get("RUNET_BENCH_ARENA") == "1":      # diagnostic: gradient arena without a process group
-        model.grad_arena()
-    step = pkg.TrainStep(model, lr=1e-4, weight_decay=1e-4, grad_sync=sync)
-    x, y = pkg.synthetic_batch(args.batch, args.size, seed=1234 + rank)
-    x, y = x.to(dev), y.to(dev)
+    graph = bool(args.graph) and not use_dist
+    step = pkg.TrainStep(model, lr=1e-4, weight_decay=1e-4, grad_sync=sync, graph=graph)
 
     def barrier():
         torch.cuda.synchronize()
@@ -148,85 +241,119 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def timed_run(batch, sync_bn, profile, warmup, steps):
+        """-> (seconds for `steps` steps: max over ranks, last loss, conv profile or None)"""
+        if sync is not None:
+            sync.set_sync_bn(sync_bn)
+        x, y = pkg.synthetic_batch(batch, args.size, seed=1234 + rank)
+        x, y = x.to(dev), y.to(dev)
+        for _ in range(warmup + (3 if graph else 0)):      # a captured step needs its eager warm-up steps + the capture itself
+            step(x, y)
+        torch.cuda.synchronize()
+        prof = ops.start_conv_profile() if profile else None
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = step(x, y)
+        barrier()
+        dt = time.perf_counter() - t0
+        roof = ops.stop_conv_profile(prof) if prof is not None else None
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        if use_dist:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()), float(loss.item()), roof
+
     if rank == 0:
-        log(f"model on {dev}, {args.warmup} warm-up + {args.steps} timed steps of {args.batch} x {args.size}x{args.size} per GPU")
-    for _ in range(args.warmup):
-        step(x, y)
-    torch.cuda.synchronize()
+        log(f"{args.model} on {dev}, {args.warmup} warm-up + {args.steps} timed steps of {args.batch} x {args.size}x{args.size} per GPU, "
+            f"{args.dtype}" + (", hipGraph step" if graph else ""))
+    want_roof = not args.no_roofline and args.model == "runet" and not graph
+    dt, final_loss, roof = timed_run(args.batch, args.sync_bn, want_roof, args.warmup, args.steps)
     if rank == 0:
-        log("warm-up done")
-    prof = None if args.no_roofline else ops.start_conv_profile()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step(x, y)
-    barrier()
-    dt = time.perf_counter() - t0
-    roof = None if prof is None else ops.stop_conv_profile(prof)
+        log(f"timed region {dt:.3f} s")
+
     alone = None
     if roof is not None and ops.USE_WGRAD_STREAM:
         # outside the timed region: three more steps with the weight gradients back on the main stream, so that the dominant kernel's
         # rate can also be quoted without a concurrent kernel sharing the GPU with it
         ops.USE_WGRAD_STREAM = False
-        step(x, y)
-        p2 = ops.start_conv_profile()
-        for _ in range(3):
-            step(x, y)
-        torch.cuda.synchronize()
-        alone = ops.stop_conv_profile(p2)["by_kernel"].get(roof["kernel"])
+        _, _, p2 = timed_run(args.batch, args.sync_bn, True, 1, 3)
+        alone = p2["by_kernel"].get(roof["kernel"])
         ops.USE_WGRAD_STREAM = True
-    t = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if use_dist:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
-    final_loss = float(loss.item())
-    if rank == 0:
-        log(f"timed region {dt:.3f} s")
+
+    extra = {}
+    if world > 1 and not args.no_extra_runs and not strong:
+        if 16 % world == 0:
+            sdt, _, _ = timed_run(16 // world, False, False, args.warmup, args.steps)
+            extra["strong"] = {"global_batch": 16, "images_per_gpu": 16 // world, "value": round(16 * args.steps / sdt, 2), "unit": "images/s",
+                               "ms_per_step": round(1e3 * sdt / args.steps, 3), "batchnorm": "per-rank statistics"}
+        if not args.sync_bn:
+            bdt, _, _ = timed_run(args.batch, True, False, args.warmup, args.steps)
+            extra["sync_bn"] = {"global_batch": world * args.batch, "value": round(world * args.batch * args.steps / bdt, 2), "unit": "images/s",
+                                "ms_per_step": round(1e3 * bdt / args.steps, 3), "batchnorm": "cross-rank statistics (equals the single-process global-batch step)"}
 
     if rank == 0:
         imgs = world * args.batch * args.steps
+        peak = PEAK_TFLOPS[args.dtype]
+        name = "Robust U-Net" if args.model == "runet" else "DeepLabV3+"
         out = {
-            "metric": "train images/sec Robust U-Net 256x256 bs16", "value": round(imgs / dt, 2), "unit": "images/s",
+            "metric": f"train images/sec {name} {args.size}x{args.size} bs{args.batch}/GPU", "value": round(imgs / dt, 2), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
-            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"Robust U-Net base{args.base} (40.9M params) train step, {args.size}x{args.size} RGB+mask tiles, "
-                                   f"batch {args.batch}/GPU, fp32, BCE + Adam(lr 1e-4, wd 1e-4), dropout + batch-stat BN on",
-                       "global_batch": world * args.batch, "image_size": args.size,
-                       "parallelism": f"dp{world}" + (f" (RCCL grad all-reduce overlapped with backward, {'SyncBN' if args.sync_bn else 'per-rank BN'})" if world > 1 else "")},
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"{name} " + (f"base{args.base} (40.9M params) " if args.model == "runet" else "") +
+                                   f"train step, {args.size}x{args.size} RGB+mask tiles, batch {args.batch}/GPU, "
+                                   + ("fp32" if args.dtype == "f32" else "bf16 matrix-core operands, fp32 accumulation / master weights / BatchNorm / Adam") +
+                                   ", BCE + Adam(lr 1e-4, wd 1e-4), dropout + batch-stat BN on" + (", hipGraph-captured step" if graph else ""),
+                       "baseline_config": args.config or 2, "global_batch": world * args.batch, "image_size": args.size,
+                       "parallelism": f"dp{world}" + (f" ({comm} gradient all-reduce overlapped with backward, "
+                                                      f"{'cross-rank' if args.sync_bn else 'per-rank'} BatchNorm statistics)" if use_dist else "")},
             "final_loss": round(final_loss, 5),
         }
+        out.update(extra)
         if roof is not None:
-            traffic = None
-            try:   # HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 cannot run inside bench.py)
-                with open(os.path.join(ROOT, "profiles", "round1_pmc_traffic.json")) as f:
-                    for name, rec in json.load(f)["kernels"].items():      # rocprof prints template arguments, the live name may not
-                        if name == roof["kernel"] or name.startswith(roof["kernel"] + "<"):
-                            traffic = rec.get("hbm_bytes_per_launch_corrected")
+            dom = roof["by_kernel"][roof["kernel"]]        # [launches, ms, algorithmic TFLOP/s, executed TFLOP/s]
+            traffic, hbm, src = None, None, TRAFFIC_FILE[args.dtype]
+            try:   # HBM bytes from the committed PMC passes
+                with open(os.path.join(ROOT, src)) as f:
+                    pmc = json.load(f)
+                for kname, rec in pmc["kernels"].items():      # rocprof prints template arguments, the live name may not
+                    if kname == roof["kernel"] or kname.startswith(roof["kernel"] + "<"):
+                        traffic = rec.get("hbm_bytes_per_launch_corrected")
+                hbm = pmc.get("step")
             except (OSError, ValueError, KeyError):
-                pass
-            out["roofline"] = {"bound": "mfma", "achieved": round(roof["tflops"], 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(roof["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                src = None
+            exec_frac = dom[3] / peak
+            out["roofline"] = {"bound": "mfma", "achieved": dom[3], "peak": peak, "unit": "TFLOP/s", "frac": round(exec_frac, 4),
+                               "algorithmic": dom[2], "algorithmic_frac": round(dom[2] / peak, 4),
+                               "step_mfma_frac": round(roof["exec_flops_total"] / args.steps / (dt / args.steps) / 1e12 / peak, 4),
+                               "traffic": traffic, "traffic_source": (src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this command, "
+                                                                      "not measured in this run)") if src else None,
                                "kernel": roof["kernel"], "launches_per_step": roof["launches"] // args.steps,
                                "avg_launch_us": round(roof["avg_us"], 2), "share_of_step": round(roof["time_s"] / dt, 3),
-                               "by_kernel": roof["by_kernel"]}
-            out["roofline"]["concurrency"] = ("weight-gradient kernels run on a second HIP stream during backward: launch durations (live events and rocprofv3 "
-                                              "alike) include time shared with them, so per-kernel rates read lower than standalone (tools/bench_conv.py, "
-                                              "tools/bench_gemm.py) while the step is faster (RUNET_NO_WGRAD_STREAM=1: 393 img/s, all rates standalone)")
-            if alone is not None:      # [launches, total ms, TFLOP/s] of the same kernel in three single-stream steps after the timed region
-                out["roofline"]["standalone"] = {"achieved": alone[2], "frac": round(alone[2] / FP32_MFMA_PEAK_TFLOPS, 4),
+                               "by_kernel": roof["by_kernel"],
+                               "by_kernel_columns": ["launches", "ms", "algorithmic TFLOP/s (direct-conv FLOPs)", "executed TFLOP/s"],
+                               "note": "achieved / frac = multiply-adds the kernel actually issues on the matrix pipe (Winograd F(2x2): 16/36, "
+                                       "F(4x4) position-GEMMs: 36/144 of the direct convolution) / HIP-event launch time; algorithmic = direct-conv FLOPs / the same time",
+                               "concurrency": "weight-gradient kernels run on a second HIP stream during backward: launch durations (live events and rocprofv3 "
+                                              "alike) include time shared with them; `standalone` repeats the measurement single-stream after the timed region"}
+            if hbm is not None:
+                out["roofline"]["hbm"] = hbm
+            if alone is not None:      # [launches, total ms, algorithmic, executed] of the same kernel in three single-stream steps after the timed region
+                out["roofline"]["standalone"] = {"achieved": alone[3], "frac": round(alone[3] / peak, 4), "algorithmic": alone[2],
                                                  "avg_launch_us": round(1e3 * alone[1] / alone[0], 2)}
-            if roof["kernel"].startswith("gemm_"):
-                out["roofline"]["note"] = ("position-GEMMs of the unfused Winograd F(4x4,3x3) path (deep 3x3 convolutions): achieved = the GEMM's own "
-                                           "2*36*tiles*K*N FLOPs / its launch time; the convolution it implements is 4x that in direct-conv FLOPs")
-            if roof["kernel"].startswith("wino"):
-                out["roofline"]["mfma_work_fraction"] = round(16.0 / 36.0, 4)
-                out["roofline"]["mfma_frac"] = round(roof["tflops"] * 16.0 / 36.0 / FP32_MFMA_PEAK_TFLOPS, 4)
-                out["roofline"]["note"] = "achieved = algorithmic (direct-conv) FLOP rate; Winograd F(2x2,3x3) runs 16/36 of the multiplies on the fp32 MFMA pipe"
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.size, 1234)
+        if world == 1 and not args.no_cpu_baseline and args.model == "runet":
+            out["cpu_baseline"] = cpu_baseline(args.batch, args.size, 1234)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    if args.selftest_launch:
+        return selftest_rank()
+    run_rank(args)
 
 
 if __name__ == "__main__":

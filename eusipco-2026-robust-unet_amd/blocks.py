@@ -52,15 +52,23 @@ _scratch = {}
 
 def scratch(nfloats, device):
     """Per-device reduction workspace (partials); grows monotonically."""
-    buf = _scratch.get(device.index)
-    if buf is None or buf.numel() < nfloats:
-        buf = torch.empty(max(int(nfloats), 1 << 21), device=device, dtype=torch.float32)
-        _scratch[device.index] = buf
-    return buf
+    return ops.grow(_scratch, device.index, nfloats, device, 1 << 21)
 
 
 def _ws(n, hw, c, device):
     return scratch(lib.runet_reduce_workspace_floats(n, hw, c), device)
+
+
+_zero_vec = {}
+
+
+def zeros(n, device):
+    """Read-only vector of zeros (eval-mode BatchNorm backward: the batch-statistics terms of dx vanish)."""
+    buf = _zero_vec.get(device.index)
+    if buf is None or buf.numel() < n:
+        buf = torch.zeros(max(int(n), 4096), device=device, dtype=torch.float32)
+        _zero_vec[device.index] = buf
+    return buf
 
 
 class DictSink:
@@ -136,10 +144,12 @@ def bn_apply(x, scale, shift, mask=None, relu=False, out=None):
     return out
 
 
-def bn_backward(dy, x, mean, invstd, scale, sums, act=None, mask=None, out=None, sync=None, relu_shift=None):
+def bn_backward(dy, x, mean, invstd, scale, sums, act=None, mask=None, out=None, sync=None, relu_shift=None, training=True):
     """sums: [2c] destination for (dgamma | dbeta), always the LOCAL sums.  act/mask: fused relu(+dropout) backward from the saved
     activation; relu_shift (the forward's shift vector, with `scale` the forward's scale): the same from x alone, act is not read.
-    sync (SyncBN): dx uses the all-reduced sums and the global element count.  -> dx"""
+    sync (SyncBN): dx uses the all-reduced sums and the global element count.  training=False (the forward normalised with the
+    RUNNING statistics, `mean` / `invstd` are those): BatchNorm is a per-channel affine map, dx = dy * scale with no batch-statistics
+    terms, while dgamma / dbeta keep their form (sums over dy * xhat and dy).  -> dx"""
     n, h, w, c = x.shape
     hw = h * w
     st = ops.stream()
@@ -153,7 +163,10 @@ def bn_backward(dy, x, mean, invstd, scale, sums, act=None, mask=None, out=None,
                                   maskp, ws.data_ptr(), sums.data_ptr(), rsc, rsh, st))
     if out is None:
         out = ops.empty_nhwc(n, h, w, c, x)
-    use, m_total = (sums, 0) if sync is None else sync.reduce_sums(sums, n * hw)
+    if not training:
+        use, m_total = zeros(2 * c, x.device), 0
+    else:
+        use, m_total = (sums, 0) if sync is None else sync.reduce_sums(sums, n * hw)
     check(lib.runet_bn_bwd_apply(dy.data_ptr(), ops.ld(dy), x.data_ptr(), ops.ld(x), actp, lda, out.data_ptr(), ops.ld(out), n * hw, hw, c,
                                  mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), use.data_ptr(), maskp, m_total, rsh, st))
     return out
@@ -214,7 +227,7 @@ def rb_forward(x, p: RBParams, training, mask=None, save=True, stats_hook=None):
                            ops.ld(out), P, hw, c, st))
     if not save:
         return out, None
-    ctx = dict(x=x, r=r, t1=t1, a1=a1, t2=t2, out=out, mask=use_mask, p=p, sync=stats_hook if training else None, s1=s1, h1=h1, mean1=mean1, invstd1=invstd1, s2=s2, h2=h2,
+    ctx = dict(x=x, r=r, t1=t1, a1=a1, t2=t2, out=out, mask=use_mask, p=p, training=training, sync=stats_hook if training else None, s1=s1, h1=h1, mean1=mean1, invstd1=invstd1, s2=s2, h2=h2,
                mean2=mean2, invstd2=invstd2, ss=ss, mean_s=mean_s, invstd_s=invstd_s, A=A, B=B, ca=ca, avg=avg, mx=mx, idx=idx,
                tval=tval, mean_nc=mean_nc, smap=smap, amax=amax, sa=sa, v1=kv1.get("V"), v2=kv2.get("V"))
     return out, ctx
@@ -253,8 +266,11 @@ def rb_backward(ctx, dout, sink, pre="", need_dx=True):
                            ctx["tval"].data_ptr(), ctx["mean2"].data_ptr(), ctx["invstd2"].data_ptr(), n, c, cr, ws.data_ptr(),
                            davg.data_ptr(), dmx.data_ptr(), sums2.data_ptr(), dw0p.data_ptr(), dw2p.data_ptr(), st))
     dt2 = ops.empty_nhwc(n, h, w, c, x)
-    sync = ctx["sync"]
-    use2, m_total = (sums2, 0) if sync is None else sync.reduce_sums(sums2, P)
+    sync, tr = ctx["sync"], ctx["training"]
+    if not tr:
+        use2, m_total = zeros(2 * c, dev), 0
+    else:
+        use2, m_total = (sums2, 0) if sync is None else sync.reduce_sums(sums2, P)
     check(lib.runet_rb_bwd3(dv.data_ptr(), ops.ld(dv), t2.data_ptr(), ops.ld(t2), sa.data_ptr(), dsm.data_ptr(), amax.data_ptr(),
                             ctx["ca"].data_ptr(), davg.data_ptr(), dmx.data_ptr(), ctx["idx"].data_ptr(), ctx["mean2"].data_ptr(),
                             ctx["invstd2"].data_ptr(), ctx["s2"].data_ptr(), use2.data_ptr(), dt2.data_ptr(), ops.ld(dt2), P, hw, c, m_total, st))
@@ -263,7 +279,7 @@ def rb_backward(ctx, dout, sink, pre="", need_dx=True):
     da1 = ops.conv_dgrad(dt2, p.w2)
     del dt2
     sums1 = sink.buf(pre, [("bn1.weight", (c,)), ("bn1.bias", (c,))])
-    dt1 = bn_backward(da1, t1, ctx["mean1"], ctx["invstd1"], ctx["s1"], sums1, mask=ctx["mask"], out=da1, sync=sync, relu_shift=ctx["h1"])
+    dt1 = bn_backward(da1, t1, ctx["mean1"], ctx["invstd1"], ctx["s1"], sums1, mask=ctx["mask"], out=da1, sync=sync, relu_shift=ctx["h1"], training=tr)
     # the first block of the network (need_dx False) ends the backward chain: nothing is left on the main stream to overlap with, so its
     # last weight gradient runs there, next to the conv2 weight gradient still on the side stream
     ops.conv_wgrad(x, dt1, 3, 3, cin_w=p.cin_w, out=sink.buf(pre, [("conv1.weight", (3, 3, p.cin_w, c))]), v=ctx.get("v1"), on_side=need_dx)
@@ -271,7 +287,7 @@ def rb_backward(ctx, dout, sink, pre="", need_dx=True):
     dx = None
     if p.ws is not None:
         sums_s = sink.buf(pre, [("shortcut.1.weight", (c,)), ("shortcut.1.bias", (c,))])
-        dr = bn_backward(dv, r, ctx["mean_s"], ctx["invstd_s"], ctx["ss"], sums_s, out=dv, sync=sync)
+        dr = bn_backward(dv, r, ctx["mean_s"], ctx["invstd_s"], ctx["ss"], sums_s, out=dv, sync=sync, training=tr)
         ops.conv_wgrad(x, dr, 1, 1, cin_w=p.cin_w, out=sink.buf(pre, [("shortcut.0.weight", (1, 1, p.cin_w, c))]))
         if need_dx:
             dx = ops.conv_dgrad(dt1, p.w1)
@@ -279,6 +295,101 @@ def rb_backward(ctx, dout, sink, pre="", need_dx=True):
     elif need_dx:
         dx = dv
         ops.conv_dgrad(dt1, p.w1, out=dx, accumulate=True)
+    return dx
+
+
+# =============================================================================== standalone attention modules
+# ChannelAttention (Main_Final.py:82-101) and SpatialAttention (:104-117) called on their own.  Inside ResidualBlock both are fused into
+# the block's tail (rb_forward); on their own they are the same kernels with an identity BatchNorm in front (scale 1, shift 0) and
+# neutral stand-ins for the other attention (per-pixel factor 1 / per-channel factor 1), so nothing new is computed differently.
+def _consts(n, c, P, dev):
+    one_c, zero_c = torch.ones(max(2 * c, n * c), device=dev), zeros(max(2 * c, n * c), dev)
+    return one_c, zero_c
+
+
+def ca_forward(x, w0p, w2p, save=True):
+    """y = x * sigmoid(mlp(avgpool x) + mlp(maxpool x)).  x NHWC.  -> (y, ctx)"""
+    n, h, w, c = x.shape
+    cr = w0p.shape[3]
+    dev, st = x.device, ops.stream()
+    sm = Small(dev)
+    mean_nc, m2_nc, max_nc, min_nc = sm.f(n * c), sm.f(n * c), sm.f(n * c), sm.f(n * c)
+    imax, imin, idx = sm.i(n * c), sm.i(n * c), sm.i(n * c)
+    check(lib.runet_chan_stats(x.data_ptr(), ops.ld(x), n, h * w, c, _ws(n, h * w, c, dev).data_ptr(), mean_nc.data_ptr(), m2_nc.data_ptr(),
+                               max_nc.data_ptr(), min_nc.data_ptr(), imax.data_ptr(), imin.data_ptr(), 1, st))
+    one, zero = _consts(n, c, 0, dev)
+    A, B, ca, avg, mx, tval = (sm.f(n * c) for _ in range(6))
+    check(lib.runet_ca_coeff(mean_nc.data_ptr(), max_nc.data_ptr(), min_nc.data_ptr(), imax.data_ptr(), imin.data_ptr(), one.data_ptr(),
+                             zero.data_ptr(), w0p.data_ptr(), w2p.data_ptr(), n, c, cr, A.data_ptr(), B.data_ptr(), ca.data_ptr(), avg.data_ptr(),
+                             mx.data_ptr(), idx.data_ptr(), tval.data_ptr(), st))
+    y = bn_apply(x, one, zero, ca, relu=False)          # (x * 1 + 0) * ca[n, c]
+    return y, (dict(x=x, w0p=w0p, w2p=w2p, ca=ca, avg=avg, mx=mx, idx=idx, tval=tval, mean_nc=mean_nc) if save else None)
+
+
+def ca_backward(ctx, dy, sink, pre=""):
+    x, w0p, w2p = ctx["x"], ctx["w0p"], ctx["w2p"]
+    n, h, w, c = x.shape
+    cr = w0p.shape[3]
+    hw, P = h * w, n * h * w
+    dev, st = x.device, ops.stream()
+    sm = Small(dev)
+    one, zero = _consts(n, c, P, dev)
+    ones_p = torch.ones(P, device=dev)
+    zeros_p2 = torch.zeros((P, 2), device=dev)
+    none_p = torch.full((P,), -1, device=dev, dtype=torch.int32)
+    sdu, sdut, davg, dmx = sm.f(n * c), sm.f(n * c), sm.f(n * c), sm.f(n * c)
+    check(lib.runet_rb_bwd2(dy.data_ptr(), ops.ld(dy), x.data_ptr(), ops.ld(x), ones_p.data_ptr(), zeros_p2.data_ptr(), none_p.data_ptr(), n, hw, c,
+                            _ws(n, hw, c, dev).data_ptr(), sdu.data_ptr(), sdut.data_ptr(), st))
+    dw0p = sink.buf(pre, [("fc.0.weight", (1, 1, c, cr))])
+    dw2p = sink.buf(pre, [("fc.2.weight", (1, 1, cr, c))])
+    sums = sm.f(2 * c)
+    ws = scratch(lib.runet_ca_bwd_workspace_floats(n, c, cr), dev)
+    check(lib.runet_ca_bwd(sdu.data_ptr(), sdut.data_ptr(), one.data_ptr(), zero.data_ptr(), ctx["ca"].data_ptr(), ctx["avg"].data_ptr(),
+                           ctx["mx"].data_ptr(), w0p.data_ptr(), w2p.data_ptr(), ctx["mean_nc"].data_ptr(), ctx["tval"].data_ptr(), zero.data_ptr(),
+                           one.data_ptr(), n, c, cr, ws.data_ptr(), davg.data_ptr(), dmx.data_ptr(), sums.data_ptr(), dw0p.data_ptr(), dw2p.data_ptr(), st))
+    dx = ops.empty_nhwc(n, h, w, c, x)
+    check(lib.runet_rb_bwd3(dy.data_ptr(), ops.ld(dy), x.data_ptr(), ops.ld(x), ones_p.data_ptr(), zeros_p2.data_ptr(), none_p.data_ptr(),
+                            ctx["ca"].data_ptr(), davg.data_ptr(), dmx.data_ptr(), ctx["idx"].data_ptr(), zero.data_ptr(), one.data_ptr(), one.data_ptr(),
+                            zero.data_ptr(), dx.data_ptr(), ops.ld(dx), P, hw, c, 0, st))
+    return dx
+
+
+def sa_forward(x, wsa, save=True):
+    """y = x * sigmoid(conv7x7([mean_c x, max_c x])).  x NHWC.  -> (y, ctx)"""
+    n, h, w, c = x.shape
+    P = n * h * w
+    dev, st = x.device, ops.stream()
+    one, zero = _consts(n, c, P, dev)
+    smap = torch.empty((P, 2), device=dev, dtype=torch.float32)
+    amax = torch.empty(P, device=dev, dtype=torch.int32)
+    check(lib.runet_sa_reduce(x.data_ptr(), ops.ld(x), one.data_ptr(), zero.data_ptr(), P, h * w, c, smap.data_ptr(), amax.data_ptr(), st))
+    sa = torch.empty(P, device=dev, dtype=torch.float32)
+    check(lib.runet_sa_conv7(smap.data_ptr(), wsa.data_ptr(), sa.data_ptr(), n, h, w, st))
+    y = ops.empty_nhwc(n, h, w, c, x)
+    check(lib.runet_mul_pixel(x.data_ptr(), ops.ld(x), sa.data_ptr(), y.data_ptr(), ops.ld(y), P, c, st))
+    return y, (dict(x=x, wsa=wsa, smap=smap, amax=amax, sa=sa) if save else None)
+
+
+def sa_backward(ctx, dy, sink, pre=""):
+    x, wsa, smap, amax, sa = ctx["x"], ctx["wsa"], ctx["smap"], ctx["amax"], ctx["sa"]
+    n, h, w, c = x.shape
+    hw, P = h * w, n * h * w
+    dev, st = x.device, ops.stream()
+    sm = Small(dev)
+    one, zero = _consts(n, c, P, dev)
+    dv = ops.empty_nhwc(n, h, w, c, x)
+    dq = torch.empty(P, device=dev, dtype=torch.float32)
+    check(lib.runet_rb_bwd1(dy.data_ptr(), ops.ld(dy), None, 0, x.data_ptr(), ops.ld(x), one.data_ptr(), zero.data_ptr(), sa.data_ptr(),
+                            dv.data_ptr(), ops.ld(dv), dq.data_ptr(), P, hw, c, st))
+    dsm = torch.empty((P, 2), device=dev, dtype=torch.float32)
+    dwsa = sink.buf(pre, [("conv1.weight", (7, 7, 2, 1))])
+    ws = scratch(lib.runet_sa_conv7_bwd_workspace_floats(n, h, w), dev)
+    check(lib.runet_sa_conv7_bwd(smap.data_ptr(), dq.data_ptr(), wsa.data_ptr(), dsm.data_ptr(), dwsa.data_ptr(), ws.data_ptr(), n, h, w, st))
+    none_nc = torch.full((n * c,), -1, device=dev, dtype=torch.int32)
+    dx = ops.empty_nhwc(n, h, w, c, x)
+    check(lib.runet_rb_bwd3(dv.data_ptr(), ops.ld(dv), x.data_ptr(), ops.ld(x), sa.data_ptr(), dsm.data_ptr(), amax.data_ptr(), one.data_ptr(),
+                            zero.data_ptr(), zero.data_ptr(), none_nc.data_ptr(), zero.data_ptr(), one.data_ptr(), one.data_ptr(), zero.data_ptr(),
+                            dx.data_ptr(), ops.ld(dx), P, hw, c, 0, st))
     return dx
 
 
@@ -304,7 +415,7 @@ def dilated_forward(x, p: DilParams, training, save=True, stats_hook=None):
     out = bn_apply(cat, s, hsh, None, relu=True)
     if not save:
         return out, None
-    return out, dict(x=x, cat=cat, out=out, p=p, s=s, h=hsh, mean=mean, invstd=invstd, sync=stats_hook if training else None)
+    return out, dict(x=x, cat=cat, out=out, p=p, s=s, h=hsh, mean=mean, invstd=invstd, training=training, sync=stats_hook if training else None)
 
 
 def dilated_backward(ctx, dout, sink, pre="", need_dx=True):
@@ -317,7 +428,7 @@ def dilated_backward(ctx, dout, sink, pre="", need_dx=True):
     wb = [sink.buf(pre, [(f"conv{i + 1}.weight", (1 if i == 0 else 3, 1 if i == 0 else 3, cin, q)), (f"conv{i + 1}.bias", (q,))])
           for i in range(4)]
     sums = sink.buf(pre, [("bn.weight", (c,)), ("bn.bias", (c,))])
-    dcat = bn_backward(dout, cat, ctx["mean"], ctx["invstd"], ctx["s"], sums, mask=None, sync=ctx["sync"], relu_shift=ctx["h"])
+    dcat = bn_backward(dout, cat, ctx["mean"], ctx["invstd"], ctx["s"], sums, mask=None, sync=ctx["sync"], relu_shift=ctx["h"], training=ctx["training"])
     dx = None
     for i in range(4):
         sl = dcat[..., i * q:(i + 1) * q]
@@ -354,7 +465,7 @@ def gate_forward(up, skip, p: UpGateParams, training, att_out, sm, stats_hook=No
                            p.wpsi.data_ptr(), p.bpsi.data_ptr(), s.data_ptr(), P, f, st))
     sp, hp, mean_p, invstd_p, _ = bn_coeff(s, p.bnp, training, sm, stats_hook=stats_hook)
     check(lib.runet_ag_out(skip.data_ptr(), ops.ld(skip), s.data_ptr(), sp.data_ptr(), hp.data_ptr(), att_out.data_ptr(), ops.ld(att_out), P, c, st))
-    return dict(sync=stats_hook if training else None, g1=g1, x1=x1, s=s, sg=sg, hg=hg, mean_g=mean_g, invstd_g=invstd_g, sx=sx, hx=hx, mean_x=mean_x, invstd_x=invstd_x,
+    return dict(training=training, sync=stats_hook if training else None, g1=g1, x1=x1, s=s, sg=sg, hg=hg, mean_g=mean_g, invstd_g=invstd_g, sx=sx, hx=hx, mean_x=mean_x, invstd_x=invstd_x,
                 sp=sp, hp=hp, mean_p=mean_p, invstd_p=invstd_p)
 
 
@@ -377,19 +488,19 @@ def gate_backward(gc, up, skip, p: UpGateParams, datt, dup, sink, pre=""):
     dsbn = torch.empty((n, h, w, 1), device=dev, dtype=torch.float32)
     check(lib.runet_ag_bwd1(datt.data_ptr(), ops.ld(datt), skip.data_ptr(), ops.ld(skip), gc["s"].data_ptr(), gc["sp"].data_ptr(),
                             gc["hp"].data_ptr(), dskip.data_ptr(), ops.ld(dskip), dsbn.data_ptr(), P, c, st))
-    sync = gc["sync"]
-    ds = bn_backward(dsbn, gc["s"], gc["mean_p"], gc["invstd_p"], gc["sp"], sums_p, out=dsbn, sync=sync)
+    sync, tr = gc["sync"], gc["training"]
+    ds = bn_backward(dsbn, gc["s"], gc["mean_p"], gc["invstd_p"], gc["sp"], sums_p, out=dsbn, sync=sync, training=tr)
     dpre = ops.empty_nhwc(n, h, w, f, skip)
     ws = _ws(n, h * w, f, dev)
     check(lib.runet_ag_bwd2(ds.data_ptr(), gc["g1"].data_ptr(), ops.ld(gc["g1"]), gc["x1"].data_ptr(), ops.ld(gc["x1"]), gc["sg"].data_ptr(),
                             gc["hg"].data_ptr(), gc["sx"].data_ptr(), gc["hx"].data_ptr(), p.wpsi.data_ptr(), dpre.data_ptr(), ops.ld(dpre),
                             ws.data_ptr(), dwpsi_db.data_ptr(), P, f, st))
-    dg1 = bn_backward(dpre, gc["g1"], gc["mean_g"], gc["invstd_g"], gc["sg"], sums_g, sync=sync)
+    dg1 = bn_backward(dpre, gc["g1"], gc["mean_g"], gc["invstd_g"], gc["sg"], sums_g, sync=sync, training=tr)
     ops.conv_wgrad(up, dg1, 1, 1, out=wg_b[:cg * f])
     chan_sum(dg1, wg_b[cg * f:])
     ops.conv_dgrad(dg1, p.wg, out=dup, accumulate=True)
     del dg1
-    dx1 = bn_backward(dpre, gc["x1"], gc["mean_x"], gc["invstd_x"], gc["sx"], sums_x, out=dpre, sync=sync)
+    dx1 = bn_backward(dpre, gc["x1"], gc["mean_x"], gc["invstd_x"], gc["sx"], sums_x, out=dpre, sync=sync, training=tr)
     ops.conv_wgrad(skip, dx1, 1, 1, out=wx_b[:c * f])
     chan_sum(dx1, wx_b[c * f:])
     ops.conv_dgrad(dx1, p.wx, out=dskip, accumulate=True)

@@ -200,7 +200,8 @@ __global__ __launch_bounds__(TPB) void rb_bwd1_kernel(const float* __restrict__ 
         float s = 0.f;
         for (int c = sub * 4; c < C; c += LPP * 4) {
             const f32x4 g = *reinterpret_cast<const f32x4*>(dout + p * lddo + c);
-            const f32x4 o = *reinterpret_cast<const f32x4*>(out + p * ldo + c);
+            f32x4 o = {1.f, 1.f, 1.f, 1.f};      // out == NULL: no ReLU behind the attention (standalone SpatialAttention)
+            if (out) o = *reinterpret_cast<const f32x4*>(out + p * ldo + c);
             const f32x4 t = *reinterpret_cast<const f32x4*>(t2 + p * ld + c);
             const f32x4 a = *reinterpret_cast<const f32x4*>(A + (long)n * C + c);
             const f32x4 b = *reinterpret_cast<const f32x4*>(B + (long)n * C + c);
@@ -685,7 +686,7 @@ extern "C" int runet_rb_out(const float* t2, int ld, const float* A, const float
 
 extern "C" int runet_rb_bwd1(const float* dout, int lddo, const float* out, int ldo, const float* t2, int ld, const float* A,
                              const float* B, const float* sa, float* dv, int lddv, float* dq, long pixels, int hw, int c, void* stream) {
-    RUNET_REQUIRE(dout && out && t2 && A && B && sa && dv && dq, "null pointer");
+    RUNET_REQUIRE(dout && t2 && A && B && sa && dv && dq, "null pointer");
     REQ_C4(c);
     hipLaunchKernelGGL(rb_bwd1_kernel, dim3(px_grid(pixels)), dim3(TPB), 0, (hipStream_t)stream, dout, lddo, out, ldo, t2, ld, A, B, sa, dv, lddv,
                        dq, pixels, hw, c);

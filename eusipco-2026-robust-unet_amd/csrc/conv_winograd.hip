@@ -616,6 +616,12 @@ extern "C" int runet_wino_supported(int h, int w, int cin, int cout) {
     return (h % 2 == 0 && w % 2 == 0 && cin % 16 == 0 && cin >= 16 && cout % 2 == 0) ? 1 : 0;
 }
 
+extern "C" int runet_wino_fits(int n_img, int h, int w, int ldx, int ldy, int cin, int cout) {
+    if (!runet_wino_supported(h, w, cin, cout)) return 0;
+    const long px = (long)n_img * h * w;
+    return (px * ldx < (1L << 29) && px * ldy < (1L << 29) && 16L * cin * cout < (1L << 29)) ? 1 : 0;
+}
+
 extern "C" int runet_wino_weights(const float* w_hwio, float* U, int cin, int cout, int dgrad, void* stream) {
     RUNET_REQUIRE(w_hwio && U && cin > 0 && cout > 0, "bad arguments");
     const long total = (long)cin * cout;
@@ -629,7 +635,7 @@ extern "C" int runet_wino_conv(const float* x, int ldx, const float* U, const fl
     RUNET_REQUIRE(runet_wino_supported(h, w, k, n), "shape not supported by the Winograd kernel (H, W even; K multiple of 16; N even)");
     RUNET_REQUIRE(ldx >= k && ldx % 2 == 0 && ldy >= n && ldy % 2 == 0, "pixel strides must be even and cover the channels");
     RUNET_REQUIRE(((uintptr_t)x % 8) == 0 && ((uintptr_t)y % 8) == 0 && ((uintptr_t)U % 16) == 0 && (!bias || ((uintptr_t)bias % 8) == 0), "alignment");
-    RUNET_REQUIRE((long)n_img * h * w * ldx < (1L << 29) && 16L * k * n < (1L << 29), "tensor too large for 32-bit buffer offsets");
+    RUNET_REQUIRE(runet_wino_fits(n_img, h, w, ldx, ldy, k, n), "tensor too large for 32-bit buffer offsets (runet_wino_fits)");
     WinoArgs a{};
     a.x = x; a.ldx = ldx; a.U = U; a.bias = bias; a.y = y; a.ldy = ldy; a.K = k; a.N = n;
     a.Nimg = n_img; a.H = h; a.W = w; a.TY = h / 2; a.TX = w / 2; a.tiles = (long)n_img * a.TY * a.TX; a.accumulate = accumulate;

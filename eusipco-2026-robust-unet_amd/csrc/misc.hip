@@ -480,3 +480,96 @@ extern "C" int runet_add_inplace(float* dst, const float* src, long n, void* str
     hipLaunchKernelGGL(add_inplace_kernel, dim3(ew_grid(n / 4 + 1)), dim3(TPB), 0, (hipStream_t)stream, dst, src, n);
     RUNET_CHECK_LAUNCH();
 }
+
+// ============================================================================================================================
+// Harness helpers: bilinear resize of the probability map when output and mask sizes differ (/root/reference/Main_Final.py:577-578,
+// 596-597,648-649; ATen upsample_bilinear2d, align_corners=False) and the per-pixel product of the standalone SpatialAttention (:117).
+namespace {
+__device__ __forceinline__ void bilin_src(int o, float scale, int in, int& i0, int& i1, float& l0, float& l1) {
+    float src = scale * ((float)o + 0.5f) - 0.5f;
+    src = src < 0.f ? 0.f : src;
+    i0 = (int)src;
+    i1 = i0 + (i0 < in - 1 ? 1 : 0);
+    l1 = src - (float)i0;
+    l0 = 1.f - l1;
+}
+__global__ __launch_bounds__(TPB) void bilinear_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long planes, int H, int W, int Ho,
+                                                           int Wo, float sh, float sw) {
+    const long total = planes * Ho * Wo;
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
+        const int ox = (int)(i % Wo);
+        const long t = i / Wo;
+        const int oy = (int)(t % Ho);
+        const float* xp = x + (t / Ho) * H * W;
+        int y0, y1, x0, x1;
+        float ly0, ly1, lx0, lx1;
+        bilin_src(oy, sh, H, y0, y1, ly0, ly1);
+        bilin_src(ox, sw, W, x0, x1, lx0, lx1);
+        y[i] = ly0 * (lx0 * xp[(long)y0 * W + x0] + lx1 * xp[(long)y0 * W + x1]) + ly1 * (lx0 * xp[(long)y1 * W + x0] + lx1 * xp[(long)y1 * W + x1]);
+    }
+}
+// adjoint, gather form: input pixel (iy, ix) collects every output pixel whose two source rows / columns include it
+__global__ __launch_bounds__(TPB) void bilinear_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, long planes, int H, int W, int Ho,
+                                                           int Wo, float sh, float sw) {
+    const long total = planes * H * W;
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
+        const int ix = (int)(i % W);
+        const long t = i / W;
+        const int iy = (int)(t % H);
+        const float* gp = dy + (t / H) * Ho * Wo;
+        // candidate outputs: src in (i - 1, i + 1)  <=>  o in ((i - 0.5) / scale - 0.5, (i + 1.5) / scale - 0.5); row 0 also takes the clamped ones
+        int oy_lo = iy == 0 ? 0 : max(0, (int)floorf(((float)iy - 0.5f) / sh - 0.5f) - 1);
+        int oy_hi = min(Ho - 1, (int)ceilf(((float)iy + 1.5f) / sh - 0.5f) + 1);
+        int ox_lo = ix == 0 ? 0 : max(0, (int)floorf(((float)ix - 0.5f) / sw - 0.5f) - 1);
+        int ox_hi = min(Wo - 1, (int)ceilf(((float)ix + 1.5f) / sw - 0.5f) + 1);
+        float acc = 0.f;
+        for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+            int y0, y1;
+            float ly0, ly1;
+            bilin_src(oy, sh, H, y0, y1, ly0, ly1);
+            const float wy = (y0 == iy ? ly0 : 0.f) + (y1 == iy ? ly1 : 0.f);
+            if (wy == 0.f) continue;
+            float row = 0.f;
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                int x0, x1;
+                float lx0, lx1;
+                bilin_src(ox, sw, W, x0, x1, lx0, lx1);
+                const float wx = (x0 == ix ? lx0 : 0.f) + (x1 == ix ? lx1 : 0.f);
+                if (wx != 0.f) row += wx * gp[(long)oy * Wo + ox];
+            }
+            acc += wy * row;
+        }
+        dx[i] = acc;
+    }
+}
+__global__ __launch_bounds__(TPB) void mul_pixel_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ s, float* __restrict__ y,
+                                                        int ldy, long P, int C) {
+    const int cvec = C / 4;
+    const long total = P * cvec;
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
+        const long p = i / cvec;
+        const int c = (int)(i - p * cvec) * 4;
+        *reinterpret_cast<f32x4*>(y + p * ldy + c) = *reinterpret_cast<const f32x4*>(x + p * ldx + c) * s[p];
+    }
+}
+}  // namespace
+
+extern "C" int runet_bilinear_fwd(const float* x, float* y, long planes, int h, int w, int ho, int wo, void* stream) {
+    RUNET_REQUIRE(x && y && planes > 0 && h > 0 && w > 0 && ho > 0 && wo > 0, "bad arguments");
+    hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(ew_grid(planes * ho * wo)), dim3(TPB), 0, (hipStream_t)stream, x, y, planes, h, w, ho, wo,
+                       (float)h / (float)ho, (float)w / (float)wo);
+    RUNET_CHECK_LAUNCH();
+}
+
+extern "C" int runet_bilinear_bwd(const float* dy, float* dx, long planes, int h, int w, int ho, int wo, void* stream) {
+    RUNET_REQUIRE(dy && dx && planes > 0 && h > 0 && w > 0 && ho > 0 && wo > 0, "bad arguments");
+    hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(ew_grid(planes * h * w)), dim3(TPB), 0, (hipStream_t)stream, dy, dx, planes, h, w, ho, wo,
+                       (float)h / (float)ho, (float)w / (float)wo);
+    RUNET_CHECK_LAUNCH();
+}
+
+extern "C" int runet_mul_pixel(const float* x, int ldx, const float* s, float* y, int ldy, long pixels, int c, void* stream) {
+    RUNET_REQUIRE(x && s && y && pixels > 0 && c > 0 && c % 4 == 0 && ldx >= c && ldy >= c, "bad arguments (c must be a multiple of 4)");
+    hipLaunchKernelGGL(mul_pixel_kernel, dim3(ew_grid(pixels * (c / 4))), dim3(TPB), 0, (hipStream_t)stream, x, ldx, s, y, ldy, pixels, c);
+    RUNET_CHECK_LAUNCH();
+}

@@ -42,8 +42,15 @@ class GradAllReducer:
         self._sent = 0
         self._work = []
         self.buckets_last_step = []
+        self._sync_bn = SyncBatchNorm(process_group) if sync_bn else None
         if sync_bn:
-            model.sync_bn_hook = SyncBatchNorm(process_group)
+            model.sync_bn_hook = self._sync_bn
+
+    def set_sync_bn(self, on):
+        """Switch between cross-rank (SyncBatchNorm) and per-rank BatchNorm statistics."""
+        if on and self._sync_bn is None:
+            self._sync_bn = SyncBatchNorm(self.group)
+        self.model.sync_bn_hook = self._sync_bn if on else None
 
     # -- wiring ------------------------------------------------------------------------------
     def attach(self, optimizer=None):
@@ -61,9 +68,27 @@ class GradAllReducer:
         return self
 
     def broadcast_parameters(self, src=0):
-        """Make every rank start from rank `src`'s parameters and buffers."""
-        for t in list(self.model.parameters()) + list(self.model.buffers()):
-            dist.broadcast(t.data if t.is_contiguous() else _dense(t), src, group=self.group)
+        """Make every rank start from rank `src`'s parameters and buffers: ONE message per dtype (fp32 parameters + BatchNorm running
+        statistics packed into a flat staging buffer, the int64 `num_batches_tracked` counters into another) instead of 290 small ones."""
+        self._broadcast(list(self.model.parameters()) + list(self.model.buffers()), src)
+
+    def broadcast_buffers(self, src=0):
+        """BatchNorm running statistics of rank `src` to every rank (per-rank statistics drift apart; torch DDP's broadcast_buffers)."""
+        self._broadcast(list(self.model.buffers()), src)
+
+    def _broadcast(self, tensors, src):
+        by_dtype = {}
+        for t in tensors:
+            by_dtype.setdefault(t.dtype, []).append(t)
+        with torch.no_grad():
+            for dtype, ts in by_dtype.items():
+                views = [_dense(t) for t in ts]
+                flat = torch.cat(views)
+                dist.broadcast(flat, src, group=self.group)
+                off = 0
+                for v in views:
+                    v.copy_(flat[off:off + v.numel()])
+                    off += v.numel()
 
     # -- per-step ----------------------------------------------------------------------------
     def _launch(self, lo, hi):
@@ -120,6 +145,8 @@ class SyncBatchNorm:
         self.world = dist.get_world_size(process_group)
 
     def gather_stats(self, mean_nc, m2_nc, n, c):
+        """Every rank must hold the same number of images `n` (all_gather into equal slots): use drop_last / equal shards, as
+        trainer.fit does under a GradAllReducer."""
         local = torch.cat([mean_nc.reshape(-1), m2_nc.reshape(-1)])
         parts = [torch.empty_like(local) for _ in range(self.world)]
         dist.all_gather(parts, local, group=self.group)
@@ -135,5 +162,5 @@ class SyncBatchNorm:
 
 
 def _dense(t):
-    """Storage-order view of a dense, permuted tensor (HWIO-stored conv weights) for collectives."""
+    """Storage-order flat view of a dense (possibly permuted: HWIO-stored conv weights) tensor for collectives."""
     return torch.as_strided(t.data, (t.numel(),), (1,), t.storage_offset())

@@ -91,7 +91,7 @@ def _conv_bn_relu(x, conv, bn, training, sm, fwd):
     raw = fwd(x, w, conv.bias)
     s, h, mean, invstd, _ = B.bn_coeff(raw, bn.state(), training, sm)
     act = B.bn_apply(raw, s, h, None, relu=True)
-    return act, dict(x=x, w=w, raw=raw, act=act, s=s, mean=mean, invstd=invstd)
+    return act, dict(x=x, w=w, raw=raw, act=act, s=s, mean=mean, invstd=invstd, training=training)
 
 
 def dl_forward(net: DeepLabV3Plus, x, save=True):
@@ -130,7 +130,7 @@ def dl_forward(net: DeepLabV3Plus, x, save=True):
     co = ops.conv_fwd(cat, ws[5], asp.conv_out.bias)
     s, hsh, mean, invstd, _ = B.bn_coeff(co, asp.bn.state(), tr, sm)
     aa = B.bn_apply(co, s, hsh, None, relu=True)
-    C["aspp"] = dict(a4=a4, cat=cat, pooled4=pooled4, ws=ws, co=co, aa=aa, s=s, mean=mean, invstd=invstd, q=q)
+    C["aspp"] = dict(a4=a4, cat=cat, pooled4=pooled4, ws=ws, co=co, aa=aa, s=s, mean=mean, invstd=invstd, q=q, training=tr)
     # ---- decoder
     y = aa
     for i in range(4):
@@ -139,7 +139,7 @@ def dl_forward(net: DeepLabV3Plus, x, save=True):
         raw = ops.convt4_fwd(y, w, ct.bias)
         s, hsh, mean, invstd, _ = B.bn_coeff(raw, bn.state(), tr, sm)
         act = B.bn_apply(raw, s, hsh, None, relu=True)
-        C[f"dec{i}"] = dict(x=y, w=w, raw=raw, act=act, s=s, mean=mean, invstd=invstd)
+        C[f"dec{i}"] = dict(x=y, w=w, raw=raw, act=act, s=s, mean=mean, invstd=invstd, training=tr)
         y = act
     head = net.decoder[12]
     wh = ops.hwio(head.weight)
@@ -163,7 +163,7 @@ def dl_backward(net: DeepLabV3Plus, C, dprob):
     def bn_back(prefix, c, dy):
         nc = c["raw"].shape[3]
         sums = torch.empty(2 * nc, device=dev, dtype=torch.float32)
-        dx = B.bn_backward(dy, c["raw"], c["mean"], c["invstd"], c["s"], sums, act=c["act"])
+        dx = B.bn_backward(dy, c["raw"], c["mean"], c["invstd"], c["s"], sums, act=c["act"], training=c["training"])
         G[prefix + ".weight"], G[prefix + ".bias"] = sums[:nc], sums[nc:]
         return dx
 
@@ -193,7 +193,7 @@ def dl_backward(net: DeepLabV3Plus, C, dprob):
     q = a["q"]
     nco = a["co"].shape[3]
     sums = torch.empty(2 * nco, device=dev, dtype=torch.float32)
-    dco = B.bn_backward(dy, a["co"], a["mean"], a["invstd"], a["s"], sums, act=a["aa"])
+    dco = B.bn_backward(dy, a["co"], a["mean"], a["invstd"], a["s"], sums, act=a["aa"], training=a["training"])
     G["aspp.bn.weight"], G["aspp.bn.bias"] = sums[:nco], sums[nco:]
     ws = a["ws"]
     cat, a4 = a["cat"], a["a4"]

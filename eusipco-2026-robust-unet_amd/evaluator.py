@@ -69,8 +69,7 @@ class ModelEvaluator:
                 images, masks = images.to(self.device, non_blocking=True), masks.to(self.device, non_blocking=True)
                 optimizer.zero_grad()
                 outputs = model(images)
-                if outputs.shape != masks.shape:
-                    raise ValueError("mask and output sizes differ; RobustUNet keeps H and W (multiples of 16)")
+                outputs = ops.match_size(outputs, masks)       # Main_Final.py:577-578
                 loss = ops.bce_loss(outputs, masks)
                 loss.backward()
                 if grad_sync is not None:
@@ -82,7 +81,7 @@ class ModelEvaluator:
             with torch.no_grad():
                 for images, masks in val_loader:
                     images, masks = images.to(self.device), masks.to(self.device)
-                    outputs = model(images)
+                    outputs = ops.match_size(model(images), masks)     # Main_Final.py:596-597
                     val_loss += ops.bce_loss(outputs, masks).item()
                     val_metrics += self.batch_metrics(outputs, masks)
             avg_train_loss = train_loss / len(train_loader)
@@ -106,7 +105,7 @@ class ModelEvaluator:
                 images, masks = images.to(self.device), masks.to(self.device)
                 torch.cuda.synchronize()
                 t0 = time.time()
-                outputs = model(images)
+                outputs = ops.match_size(model(images), masks)     # Main_Final.py:648-649 (inside the timed span, as in the reference)
                 torch.cuda.synchronize()
                 inference_times.append((time.time() - t0) / images.shape[0])
                 all_metrics += self.batch_metrics(outputs, masks)

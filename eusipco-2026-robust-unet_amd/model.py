@@ -125,7 +125,7 @@ def _require_cuda(x):
 
 # ----------------------------------------------------------------------------- attention modules
 class ChannelAttention(nn.Module):
-    """Parameter layout of the reference module; the computation is fused into ResidualBlock."""
+    """Parameter layout and call surface of the reference module (Main_Final.py:82-101)."""
 
     def __init__(self, in_channels, ratio=16):
         super().__init__()
@@ -135,7 +135,23 @@ class ChannelAttention(nn.Module):
         self.sigmoid = _Act()
 
     def forward(self, x):
-        raise NotImplementedError("ChannelAttention is fused into ResidualBlock's kernels (bn2 -> ca -> sa -> +res -> relu)")
+        """Standalone call (inside ResidualBlock the same kernels run fused into the block's tail)."""
+        _require_cuda(x)
+        return _CAFn.apply(x, self.fc[0].weight, self.fc[2].weight)
+
+
+class _CAFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w0, w2):
+        y, ctx.c = B.ca_forward(_nhwc(x), ops.hwio(w0), ops.hwio(w2))
+        return _nchw(y)
+
+    @staticmethod
+    def backward(ctx, dy):
+        sink = B.DictSink(dy.device)
+        dx = B.ca_backward(ctx.c, _nhwc(dy), sink)
+        ctx.c = None
+        return _nchw(dx), _logical("fc.0.weight", sink.g["fc.0.weight"]), _logical("fc.2.weight", sink.g["fc.2.weight"])
 
 
 class SpatialAttention(nn.Module):
@@ -146,7 +162,23 @@ class SpatialAttention(nn.Module):
         self.sigmoid = _Act()
 
     def forward(self, x):
-        raise NotImplementedError("SpatialAttention is fused into ResidualBlock's kernels (bn2 -> ca -> sa -> +res -> relu)")
+        """Standalone call (inside ResidualBlock the same kernels run fused into the block's tail)."""
+        _require_cuda(x)
+        return _SAFn.apply(x, self.conv1.weight)
+
+
+class _SAFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w):
+        y, ctx.c = B.sa_forward(_nhwc(x), ops.hwio(w))
+        return _nchw(y)
+
+    @staticmethod
+    def backward(ctx, dy):
+        sink = B.DictSink(dy.device)
+        dx = B.sa_backward(ctx.c, _nhwc(dy), sink)
+        ctx.c = None
+        return _nchw(dx), _logical("conv1.weight", sink.g["conv1.weight"])
 
 
 class AttentionGate(nn.Module):

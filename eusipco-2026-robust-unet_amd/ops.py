@@ -15,6 +15,21 @@ from ._lib import check, lib
 CONV_FWD, CONV_DGRAD, CONVT_FWD, CONVT_DGRAD = 0, 1, 2, 3
 
 _ws = {}
+# Set by trainer.TrainStep once a step has been captured into a hipGraph: the graph holds the ADDRESSES of the scratch buffers, so a
+# later, larger eager step (ragged batch, another model) must not free them when it grows a pool - superseded buffers are retired here.
+PIN_SCRATCH = False
+_retired = []
+
+
+def grow(pool, key, nfloats, device, floor):
+    """Scratch buffer `key` of `pool` with at least `nfloats` floats (grows geometrically; see PIN_SCRATCH)."""
+    buf = pool.get(key)
+    if buf is None or buf.numel() < nfloats:
+        if buf is not None and PIN_SCRATCH:
+            _retired.append(buf)
+        buf = torch.empty(max(int(nfloats), floor, 2 * buf.numel() if buf is not None else 0), device=device, dtype=torch.float32)
+        pool[key] = buf
+    return buf
 
 
 def stream():
@@ -36,11 +51,7 @@ def empty_nhwc(n, h, w, c, like):
 
 def workspace(nfloats, device):
     key = (device.index, "wgrad", torch.cuda.current_stream().cuda_stream)      # one scratch per stream (weight gradients may run on a side stream)
-    buf = _ws.get(key)
-    if buf is None or buf.numel() < nfloats:
-        buf = torch.empty(max(nfloats, 1 << 22), device=device, dtype=torch.float32)
-        _ws[key] = buf
-    return buf
+    return grow(_ws, key, nfloats, device, 1 << 22)
 
 
 def hwio(w):
@@ -67,20 +78,25 @@ def start_conv_profile():
 
 
 def stop_conv_profile(prof):
-    """-> dict(kernel=dominant instantiation, tflops, avg_us, launches, time_s, by_kernel={name: [launches, ms, TFLOP/s]})"""
+    """-> dict(kernel=dominant instantiation, avg_us, launches, time_s, exec_flops_total,
+               by_kernel={name: [launches, ms, algorithmic TFLOP/s, executed TFLOP/s]})
+    algorithmic = the direct convolution's FLOPs; executed = the multiply-adds the kernel issues on the
+    matrix pipe (Winograd F(2x2): 16/36 of them, F(4x4) position-GEMMs: their own GEMM FLOPs)."""
     global _PROFILE
     _PROFILE = None
     torch.cuda.synchronize()
     agg = {}
-    for name, flops, e0, e1 in prof:
-        a = agg.setdefault(name, [0, 0.0, 0.0])
+    for name, flops, xflops, e0, e1 in prof:
+        a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
         a[0] += 1
         a[1] += e0.elapsed_time(e1) * 1e-3
         a[2] += flops
+        a[3] += xflops
     dom = max(agg, key=lambda k: agg[k][1])
-    n, t, f = agg[dom]
-    by = {k: [v[0], round(v[1] * 1e3, 3), round(v[2] / v[1] / 1e12, 2)] for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
-    return {"kernel": dom, "tflops": f / t / 1e12, "avg_us": t / n * 1e6, "launches": n, "time_s": t, "by_kernel": by}
+    n, t, f, xf = agg[dom]
+    by = {k: [v[0], round(v[1] * 1e3, 3), round(v[2] / v[1] / 1e12, 2), round(v[3] / v[1] / 1e12, 2)]
+          for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
+    return {"kernel": dom, "avg_us": t / n * 1e6, "launches": n, "time_s": t, "exec_flops_total": sum(v[3] for v in agg.values()), "by_kernel": by}
 
 
 def _igemm(mode, x, ldx, w, bias, y, ldy, n, h, wd, cin, cin_w, cout, kh, kw, dil, accumulate):
@@ -93,14 +109,17 @@ def _igemm(mode, x, ldx, w, bias, y, ldy, n, h, wd, cin, cin_w, cout, kh, kw, di
     e1.record()
     taps = 4 if kh == 2 else kh * kw
     name = lib.runet_conv_igemm_kernel_name(n, h, wd, cout, mode).decode()
-    _PROFILE.append((name, 2.0 * n * h * wd * taps * min(cin, cin_w) * cout, e0, e1))
+    fl = 2.0 * n * h * wd * taps * min(cin, cin_w) * cout
+    _PROFILE.append((name, fl, fl, e0, e1))
 
 
 USE_WINOGRAD = os.environ.get("RUNET_NO_WINOGRAD", "0") != "1"
 
 
-def _wino_case(h, w, kh, dil, k, n, cin_w):
-    return USE_WINOGRAD and kh == 3 and dil == 1 and cin_w == k and bool(lib.runet_wino_supported(h, w, k, n))
+def _wino_case(h, w, kh, dil, k, n, cin_w, n_img=1, ldx=0, ldy=0):
+    """Fused F(2x2) kernel usable: shape supported and the tensors within its 32-bit buffer offsets (else: implicit GEMM, 64-bit)."""
+    return (USE_WINOGRAD and kh == 3 and dil == 1 and cin_w == k
+            and bool(lib.runet_wino_fits(n_img, h, w, max(ldx, k), max(ldy, n), k, n)))
 
 
 USE_WINOGRAD4 = USE_WINOGRAD and os.environ.get("RUNET_NO_WINOGRAD4", "0") != "1"
@@ -117,7 +136,7 @@ def conv_fwd(x, w_hwio, bias=None, out=None, dil=1, accumulate=False, keep_v=Non
     kh, kw, cin_w, cout = w_hwio.shape
     if _wino4_case(h, w, kh, dil, cin, cout, cin_w):
         return wino4_conv(x, wino4_weights(w_hwio), bias, out=out, accumulate=accumulate, keep_v=keep_v)
-    if _wino_case(h, w, kh, dil, cin, cout, cin_w):
+    if _wino_case(h, w, kh, dil, cin, cout, cin_w, n, ld(x), ld(out) if out is not None else cout):
         return wino_conv(x, wino_weights(w_hwio), bias, out=out, accumulate=accumulate)
     if out is None:
         out = empty_nhwc(n, h, w, cout, x)
@@ -148,7 +167,8 @@ def wino_conv(x, U, bias=None, out=None, accumulate=False):
                               n, h, w, k, nn_, int(accumulate), stream()))
     if _PROFILE is not None:
         e1.record()
-        _PROFILE.append(("wino_conv_kernel", 2.0 * n * h * w * 9 * k * nn_, e0, e1))
+        fl = 2.0 * n * h * w * 9 * k * nn_
+        _PROFILE.append(("wino_conv_kernel", fl, fl * 16.0 / 36.0, e0, e1))
     return out
 
 
@@ -162,7 +182,7 @@ def conv_dgrad(dy, w_hwio, out=None, dil=1, accumulate=False):
     assert cout_w == cout
     if _wino4_case(h, w, kh, dil, cout, cin, cout):
         return wino4_conv(dy, wino4_weights(w_hwio, dgrad=True), None, out=out, accumulate=accumulate)
-    if _wino_case(h, w, kh, dil, cout, cin, cout):
+    if _wino_case(h, w, kh, dil, cout, cin, cout, n, ld(dy), ld(out) if out is not None else cin):
         return wino_conv(dy, wino_weights(w_hwio, dgrad=True), None, out=out, accumulate=accumulate)
     if out is None:
         out = empty_nhwc(n, h, w, cin, dy)
@@ -247,7 +267,8 @@ def _conv_wgrad(x, dy, kh, kw, cin_w=None, dil=1, out=None, v=None):
                                    n, h, w, cin, cin_w, cout, kh, kw, dil, 0, stream()))
     if prof:
         e1.record()
-        _PROFILE.append((name, 2.0 * n * h * w * kh * kw * cin_w * cout, e0, e1))
+        fl = 2.0 * n * h * w * kh * kw * cin_w * cout
+        _PROFILE.append((name, fl, fl * 16.0 / 36.0 if name.startswith("wino") else fl, e0, e1))
     return out
 
 
@@ -321,6 +342,42 @@ def bce_loss(prob, target):
     if prob.shape != target.shape:
         raise ValueError(f"shape mismatch {tuple(prob.shape)} vs {tuple(target.shape)}")
     return _BCELoss.apply(prob, target.to(torch.float32))
+
+
+class _Bilinear(torch.autograd.Function):
+    """F.interpolate(x, size, mode='bilinear', align_corners=False) on [N, C, H, W] device tensors (the reference's harness resizes
+    the model output to the mask size when they differ: /root/reference/Main_Final.py:577-578,596-597,648-649)."""
+
+    @staticmethod
+    def forward(ctx, x, size):
+        x = x.contiguous()
+        n, c, h, w = x.shape
+        ho, wo = int(size[0]), int(size[1])
+        y = torch.empty((n, c, ho, wo), device=x.device, dtype=torch.float32)
+        check(lib.runet_bilinear_fwd(x.data_ptr(), y.data_ptr(), n * c, h, w, ho, wo, stream()))
+        ctx.shape = (n, c, h, w, ho, wo)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, c, h, w, ho, wo = ctx.shape
+        dy = dy.contiguous()
+        dx = torch.empty((n, c, h, w), device=dy.device, dtype=torch.float32)
+        check(lib.runet_bilinear_bwd(dy.data_ptr(), dx.data_ptr(), n * c, h, w, ho, wo, stream()))
+        return dx, None
+
+
+def bilinear_resize(x, size):
+    if not x.is_cuda or x.dtype != torch.float32 or x.dim() != 4:
+        raise RuntimeError("bilinear_resize takes a float32 [N, C, H, W] HIP-device tensor")
+    return _Bilinear.apply(x, tuple(size))
+
+
+def match_size(outputs, masks):
+    """The reference harness's size guard: outputs resized to the mask's H x W when the shapes differ."""
+    if outputs.shape != masks.shape:
+        outputs = bilinear_resize(outputs, masks.shape[-2:])
+    return outputs
 
 
 def seg_counts(pred, target, threshold=0.5):
@@ -408,11 +465,7 @@ _ws4 = {}
 
 def _workspace4(nfloats, device):
     key = (device.index, torch.cuda.current_stream().cuda_stream)
-    buf = _ws4.get(key)
-    if buf is None or buf.numel() < nfloats:
-        buf = torch.empty(int(nfloats), device=device, dtype=torch.float32)
-        _ws4[key] = buf
-    return buf
+    return grow(_ws4, key, nfloats, device, 1)
 
 
 def wino4_ok(h, w, k, n):
@@ -457,7 +510,8 @@ def wino4_conv(x, U, bias=None, out=None, accumulate=False, keep_v=None):
     check(lib.runet_gemm_batched(V, k, t * k, U.data_ptr(), k * nn_, M, nn_, t * nn_, 36, t, k, nn_, stream()))
     if _PROFILE is not None:
         e1.record()
-        _PROFILE.append((lib.runet_gemm_batched_kernel_name(36, t, k, nn_).decode(), 2.0 * 36 * t * k * nn_, e0, e1))
+        fl = 2.0 * 36 * t * k * nn_          # the position-GEMMs' own FLOPs; the convolution they implement is 4x that in direct-conv FLOPs
+        _PROFILE.append((lib.runet_gemm_batched_kernel_name(36, t, k, nn_).decode(), 4.0 * fl, fl, e0, e1))
     check(lib.runet_wino4_output(M, nn_, n, h, w, bp, out.data_ptr(), ld(out), int(accumulate), stream()))
     return out
 
@@ -489,6 +543,7 @@ def wino4_wgrad(x, dy, out=None, v=None):
     check(lib.runet_gemm_tn_batched(V, cin, t * cin, Z, cout, t * cout, dU, 36, t, cin, cout, rps, stream()))
     if _PROFILE is not None:
         e1.record()
-        _PROFILE.append(("gemm_tn_kernel", 2.0 * 36 * t * cin * cout, e0, e1))
+        fl = 2.0 * 36 * t * cin * cout
+        _PROFILE.append(("gemm_tn_kernel", 4.0 * fl, fl, e0, e1))
     check(lib.runet_wino4_wgrad_output(dU, -(-t // rps), cin, cout, out.data_ptr(), stream()))
     return out

@@ -32,7 +32,7 @@ class TrainStep:
 
     def _body(self, images, masks):
         self.optimizer.zero_grad(set_to_none=True)
-        prob = self.model(images)
+        prob = ops.match_size(self.model(images), masks)
         loss = ops.bce_loss(prob, masks)
         loss.backward()
         if self.grad_sync is not None:
@@ -53,6 +53,7 @@ class TrainStep:
             self._static = [images.clone(), masks.clone(), None]
             self.optimizer.sync_hyper()
             torch.cuda.synchronize()
+            ops.PIN_SCRATCH = True        # the graph bakes in scratch addresses: pools may grow later but never free what it uses
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self._static[2] = self._body(self._static[0], self._static[1])
@@ -72,7 +73,10 @@ def fit(model, train_loader, val_loader, device, epochs=200, lr=1e-4, weight_dec
     (/root/reference/train_water_segmentation.py:514-645) around the Robust U-Net step:
     ReduceLROnPlateau(factor 0.5, patience `lr_patience`) stepped on the VALIDATION loss, the state_dict of the best
     validation IoU saved to `<save_dir>/best_water_segmentation_model.pth`, early stop after `stop_patience` epochs without an
-    IoU improvement.  The checkpoint holds plain contiguous OIHW tensors under the reference's keys, so the reference's
+    IoU improvement.  Under a `grad_sync` (one process per GPU) every rank takes the same decisions: ragged batches are dropped (all
+    ranks run the same number of equal-sized steps), the BatchNorm running statistics of rank 0 are broadcast before each
+    validation pass, validation loss / IoU / accuracy are averaged over the ranks before the scheduler and the early-stop test see
+    them, and only rank 0 writes the checkpoint and the history.  The checkpoint holds plain contiguous OIHW tensors under the reference's keys, so the reference's
     `RobustUNet.load_state_dict(torch.load(path))` accepts it.  History keys follow the reference (`train_losses`,
     `val_losses`, `accuracies`, `iou_scores`, `learning_rates`, `best_model_epoch`, `training_time`); it is written as JSON
     (the reference pickles it).  Validation IoU / accuracy are the mean of Main_Final.py's per-image metrics."""
@@ -82,6 +86,7 @@ def fit(model, train_loader, val_loader, device, epochs=200, lr=1e-4, weight_dec
 
     import numpy as np
     import torch
+    import torch.distributed as dist
 
     from .data import DevicePrefetcher
     from .evaluator import ModelEvaluator
@@ -94,21 +99,34 @@ def fit(model, train_loader, val_loader, device, epochs=200, lr=1e-4, weight_dec
             "training_time": 0.0}
     best_iou, waited, t0 = 0.0, 0, time.time()
     ckpt = os.path.join(save_dir, "best_water_segmentation_model.pth")
+    multi = grad_sync is not None and dist.is_initialized() and grad_sync.world > 1
+    writer = not multi or dist.get_rank(grad_sync.group) == 0
+    full_batch = None
     for epoch in range(epochs):
         model.train()
         losses = []
         for images, masks in DevicePrefetcher(train_loader, device):
+            if full_batch is None:
+                full_batch = images.shape[0]
+            if multi and images.shape[0] != full_batch:
+                continue                                       # drop_last: a ragged step would desynchronise the ranks' collectives
             losses.append(step(images, masks))                 # device scalars: one host sync per epoch, not per step
         train_loss = float(torch.stack(losses).mean().item())
+        if multi:
+            grad_sync.broadcast_buffers(0)
         model.eval()
         vloss, mets = [], []
         with torch.no_grad():
             for images, masks in DevicePrefetcher(val_loader, device):
-                prob = model(images)
+                prob = ops.match_size(model(images), masks)
                 vloss.append(ops.bce_loss(prob, masks))
                 mets += ev.batch_metrics(prob, masks)
         val_loss = float(torch.stack(vloss).mean().item())
         iou, acc = float(np.mean([m["iou"] for m in mets])), float(np.mean([m["accuracy"] for m in mets]))
+        if multi:       # every rank must see the same numbers: the LR schedule and the early stop are collective decisions
+            agg = torch.tensor([train_loss, val_loss, iou, acc], dtype=torch.float64, device=device if dist.get_backend(grad_sync.group) == "nccl" else "cpu")
+            dist.all_reduce(agg, op=dist.ReduceOp.SUM, group=grad_sync.group)
+            train_loss, val_loss, iou, acc = (agg / grad_sync.world).tolist()
         sched.step(val_loss)
         hist["train_losses"].append(train_loss)
         hist["val_losses"].append(val_loss)
@@ -118,7 +136,8 @@ def fit(model, train_loader, val_loader, device, epochs=200, lr=1e-4, weight_dec
         if iou > best_iou:
             best_iou, waited = iou, 0
             hist["best_model_epoch"] = epoch
-            torch.save({k: v.detach().cpu().contiguous() for k, v in model.state_dict().items()}, ckpt)
+            if writer:
+                torch.save({k: v.detach().cpu().contiguous() for k, v in model.state_dict().items()}, ckpt)
         else:
             waited += 1
         log(f"epoch {epoch + 1}/{epochs}: train {train_loss:.4f} val {val_loss:.4f} IoU {iou:.4f} acc {acc:.4f} "
@@ -127,6 +146,7 @@ def fit(model, train_loader, val_loader, device, epochs=200, lr=1e-4, weight_dec
             log(f"early stop: {stop_patience} epochs without IoU improvement")
             break
     hist["training_time"] = time.time() - t0
-    with open(os.path.join(save_dir, "training_history.json"), "w") as f:
-        json.dump(hist, f)
+    if writer:
+        with open(os.path.join(save_dir, "training_history.json"), "w") as f:
+            json.dump(hist, f)
     return hist

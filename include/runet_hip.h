@@ -59,6 +59,9 @@ int runet_conv_wgrad(const float* x, int ldx, const float* dy, int ldy, float* d
  * filter with K = cout, N = cin (so that runet_wino_conv(dy, U') is the data gradient).
  * runet_wino_conv: y[n,h,w,0:N] (=|+=) bias + winograd_conv(x[n,h,w,0:K], U).  Needs H, W even, K % 16 == 0, N even. */
 int runet_wino_supported(int h, int w, int cin, int cout);
+/* shape supported AND the tensors fit the kernel's 32-bit buffer offsets (n_img*h*w*ld < 2^29 floats): callers fall back to
+ * runet_conv_igemm (64-bit addressing) when this is 0, e.g. 16 x 512 x 512 with a 128-channel concat input */
+int runet_wino_fits(int n_img, int h, int w, int ldx, int ldy, int cin, int cout);
 int runet_wino_weights(const float* w_hwio, float* U, int cin, int cout, int dgrad, void* stream);
 int runet_wino_conv(const float* x, int ldx, const float* U, const float* bias, float* y, int ldy, int n_img, int h, int w, int k, int n,
                     int accumulate, void* stream);
@@ -114,6 +117,7 @@ int runet_sa_conv7(const float* smap, const float* wp, float* sa, int n_img, int
 /* out = relu((t2*A[n,c]+B[n,c])*sa[p] + res),  res = r*rs[c]+rh[c]  (rs == NULL: res = r, identity shortcut) */
 int runet_rb_out(const float* t2, int ld, const float* A, const float* B, const float* sa, const float* r, int ldr, const float* rs,
                  const float* rh, float* out, int ldo, long pixels, int hw, int c, void* stream);
+/* dv = dout * (out > 0) (out NULL: dv = dout, no ReLU behind the attention), dq[p] = (sum_c dv*u) * sa*(1-sa) with u = t2*A+B */
 int runet_rb_bwd1(const float* dout, int lddo, const float* out, int ldo, const float* t2, int ld, const float* A, const float* B,
                   const float* sa, float* dv, int lddv, float* dq, long pixels, int hw, int c, void* stream);
 long runet_sa_conv7_bwd_workspace_floats(int n_img, int h, int w);
@@ -229,6 +233,17 @@ int runet_head3x3_fwd(const float* x, int ld, const float* w, const float* b, fl
 long runet_head3x3_bwd_workspace_floats(int n_img, int h, int w_, int c);
 int runet_head3x3_bwd(const float* dprob, const float* prob, const float* x, int ld, const float* w, float* dx, int lddx, float* workspace,
                       float* dw_db, int n_img, int h, int w_, int c, void* stream);
+
+
+/* ---- harness helpers (Main_Final.py:577-578,596-597,648-649: `F.interpolate(outputs, size=masks.shape[-2:], mode='bilinear',
+ *      align_corners=False)` when the model output and the mask differ in size; :82-117 standalone attention modules) ----
+ * runet_bilinear_fwd: y[planes, ho, wo] = bilinear resize of x[planes, h, w] with ATen's align_corners=False source index
+ *   (src = max(0, (dst + 0.5) * in/out - 0.5)).  runet_bilinear_bwd: dx[planes, h, w] = its adjoint applied to dy[planes, ho, wo]
+ *   (gather form: fixed summation order, no atomics).
+ * runet_mul_pixel: y[p, 0:c] = x[p, 0:c] * s[p]  (NHWC, one factor per pixel: SpatialAttention's output product). */
+int runet_bilinear_fwd(const float* x, float* y, long planes, int h, int w, int ho, int wo, void* stream);
+int runet_bilinear_bwd(const float* dy, float* dx, long planes, int h, int w, int ho, int wo, void* stream);
+int runet_mul_pixel(const float* x, int ldx, const float* s, float* y, int ldy, long pixels, int c, void* stream);
 
 #ifdef __cplusplus
 }

@@ -13,6 +13,8 @@ import numpy as np
 import pytest
 import torch
 
+import decisions as D
+
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
@@ -129,7 +131,39 @@ def test_two_full_size_tiles_against_the_oracle(pkg, oracle):
         a = ev.calculate_metrics(prob[i, 0].detach(), y[i, 0].to(DEV))
         b = oracle.seg_metrics(rp[i, 0].detach(), y[i, 0])
         assert abs(a["iou"] - b["iou"]) <= 1e-3 and abs(a["f1_score"] - b["f1_score"]) <= 1e-3
-    gn = np.array([p.grad.double().norm().item() for p in model.parameters()])
-    rn = np.array([P[k].grad.double().norm().item() for k in names])
-    rel = np.abs(gn - rn) / (rn + 1e-3 * rn.max())
-    assert rel.max() < 2e-2, (names[int(rel.argmax())], gn[int(rel.argmax())], rn[int(rel.argmax())])
+    # gradients: decision-aware (tests/decisions.py): ReLU masks may differ only at near-ties, and under the same masks every gradient
+    # tensor is within 2e-4 of its scale (was: 2e-2 on the norms)
+    D.check_step(pkg, oracle, 64, n, seed, x, y, tol=2e-4, median_tol=2e-5)
+
+
+@pytest.mark.parametrize("n,size", [(4, 512), (1, 1024)])
+def test_train_step_at_config3_and_config5_shapes(pkg, oracle, n, size):
+    """BASELINE.json config 3's per-GPU shard (4 x 512^2) and config 5's tile (1 x 1024^2) as TRAIN steps (fp32): two identical steps are
+    bit-identical, and one fused-Adam step moves the parameters the way the gradient says (every kernel of the path at these sizes)."""
+    model = _model(pkg, oracle, seed=23).train()
+    model.set_dropout_masks({k: v.to(DEV) for k, v in oracle.dropout_masks(n, 64, seed=7).items()})
+    x, y = pkg.synthetic_batch(n, size, seed=35)
+    x, y = x.to(DEV), y.to(DEV)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    l1, g1, p1 = _step_grads(pkg, model, x, y)
+    model.load_state_dict(sd)
+    l2, g2, p2 = _step_grads(pkg, model, x, y)
+    assert torch.equal(p1, p2) and torch.equal(l1, l2) and bool(torch.isfinite(l1))
+    for a, b in zip(g1, g2):
+        assert torch.equal(a, b) and bool(torch.isfinite(a).all())
+    opt = pkg.FusedAdam(model.parameters(), lr=1e-4, weight_decay=0.0)
+    before = [p.detach().clone() for p in model.parameters()]
+    opt.step()
+    for b, p, g in zip(before, model.parameters(), g1):      # first Adam step: -lr * sign(g) wherever |g| >> eps
+        big = g.abs() > 1e-5
+        if bool(big.any()):
+            assert torch.allclose((p.detach() - b)[big], -1e-4 * torch.sign(g[big]), rtol=2e-3, atol=0)
+
+
+@pytest.mark.parametrize("n,size,seed", [(2, 512, 43), (1, 1024, 45)])
+def test_large_tiles_against_the_oracle(pkg, oracle, n, size, seed):
+    """A 512^2 pair (config 3's tile size) and ONE 1024^2 tile (config 5) as train steps against the CPU oracle: probabilities within 1e-3,
+    ReLU masks differing only at near-ties, every gradient tensor within 2e-4 of its scale under the same masks (tests/decisions.py)."""
+    torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
+    x, y = pkg.synthetic_batch(n, size, seed=seed)
+    D.check_step(pkg, oracle, 64, n, seed, x, y, tol=2e-4, median_tol=2e-5)

@@ -68,3 +68,28 @@ def test_graph_step_timing_report(pkg, oracle):
     # reported, not asserted (timing on a shared box): eager 11.6-11.9 ms (weight gradients on their side stream), replay 12.3-12.8 ms
     # (single captured stream) - the step is bound by its ~650 short kernels, not by their launches
     assert out[True] > 0 and out[False] > 0
+
+
+def test_graph_replay_at_config5_tile(pkg, oracle):
+    """BASELINE.json config 5: one 1024 x 1024 tile per GPU through the hipGraph-captured step - replayed losses and parameters
+    bit-identical to the eager step's."""
+    trainer = importlib.import_module("eusipco-2026-robust-unet_amd.trainer")
+    res = {}
+    for graph in (False, True):
+        m = pkg.RobustUNet(3, 1, 64)
+        m.load_state_dict(oracle.init_state(3, 1, 64, seed=8, perturb_bn=True))
+        m = m.to(DEV).train()
+        m.set_dropout_masks({k: v.to(DEV) for k, v in oracle.dropout_masks(1, 64, seed=8).items()})
+        step = trainer.TrainStep(m, lr=1e-4, weight_decay=1e-4, graph=graph, graph_warmup=1)
+        step.optimizer.capturable = True
+        losses = []
+        for i in range(4):
+            x, y = pkg.synthetic_batch(1, 1024, seed=70 + i)
+            losses.append(step(x.to(DEV), y.to(DEV)).detach().clone())
+        res[graph] = (losses, [p.detach().clone() for p in m.parameters()])
+        if graph:
+            assert step._graph is not None
+    for a, b in zip(res[False][0], res[True][0]):
+        assert torch.equal(a, b)
+    for a, b in zip(res[False][1], res[True][1]):
+        assert torch.equal(a, b)

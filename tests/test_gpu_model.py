@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 import torch
 
+import decisions as D
 from conftest import GOLDEN, load_npz
 
 pytestmark = pytest.mark.gpu
@@ -58,14 +59,14 @@ def test_train_step_matches_reference(pkg, oracle, tag):
                 # conv bias in front of a train-mode BatchNorm: analytically zero gradient, rounding noise on both sides
                 assert np.abs(gref).max() <= 1e-5 * ref.max() and p.grad.abs().max().item() <= 1e-5 * ref.max(), k
                 continue
-            # element-wise: 5e-3 of the tensor's scale; a handful of elements may move more when a ReLU / max-pool /
-            # channel-argmax decision sits within rounding distance of a tie (discontinuous ops), so allow <= 1 %
-            # of the elements up to 3e-2 of the scale
+            # element-wise against the FIXED golden gradients.  The b64 golden input carries three ReLU near-ties (dec3 out (1,34,0,1):
+            # -1.3e-7, dec1 bn1 (1,44,63,20): -1.2e-6, dec1 out (1,22,47,63): -7.7e-7 on tensors of scale 6-9) that the HIP step
+            # takes the other way, exactly as the reference does to itself with oneDNN on / off (tests/diagnostics/decision_flips.py:
+            # same median 6e-4..1.2e-3, same worst tensors).  The tight gradient check, free of that lottery, is
+            # test_gradients_match_oracle_under_the_same_relu_decisions below (1e-4 of scale); this one keeps the loose band.
             scale = float(np.abs(gref).max()) + 1e-7 * float(ref.max())
             err = np.abs(p.grad.cpu().numpy() - gref)
             assert err.max() <= 3e-2 * scale, (k, err.max(), scale)
-            # tools/parity_report.py: the b64 case carries one flipped ReLU/max decision (median error 1e-3 of scale for EVERY conv
-            # algorithm, direct included; the b16 case sits at 2e-6), so a few per cent of a small tensor may land in the wide band
             allowed = max(1, int(0.05 * err.size))
             assert int((err > 5e-3 * scale).sum()) <= allowed, (k, int((err > 5e-3 * scale).sum()), err.size)
     for k, b in model.named_buffers():
@@ -174,10 +175,8 @@ def test_rectangular_and_minimum_sizes_against_the_oracle(pkg, oracle, n, h, w, 
     lg = rl.detach().numpy()
     np.testing.assert_allclose(logit.detach().cpu().numpy(), lg, rtol=1e-3, atol=1e-3 * max(1.0, float(np.abs(lg).max()) / 10))
     assert abs(float(loss.detach()) - float(rloss.detach())) <= 1e-3 * max(1.0, abs(float(rloss.detach())))
-    gn = np.array([p.grad.double().norm().item() for p in model.parameters()])
-    rn = np.array([P[k].grad.double().norm().item() for k in names])
-    rel = np.abs(gn - rn) / (rn + 1e-3 * rn.max())
-    assert rel.max() < 3e-2, (names[int(rel.argmax())], gn[int(rel.argmax())], rn[int(rel.argmax())])
+    # gradients: decision-aware (near-tie ReLU flips forced into the oracle), 1e-4 of each tensor's scale instead of 3e-2 on norms
+    D.check_step(pkg, oracle, base, n, seed, x, y, tol=1e-4, median_tol=2e-5)
 
 
 def test_single_value_per_channel_in_training_raises_like_torch(pkg):
@@ -192,3 +191,20 @@ def test_single_value_per_channel_in_training_raises_like_torch(pkg):
     model.eval()
     with torch.no_grad():
         assert model(x).shape == (1, 1, 16, 16)
+
+
+@pytest.mark.parametrize("base,n,size,seed", [(16, 2, 64, 3), (64, 2, 64, 5), (64, 2, 64, 12), (32, 3, 32, 21)])
+def test_gradients_match_oracle_under_the_same_relu_decisions(pkg, oracle, base, n, size, seed):
+    """All 173 gradient tensors within 1e-4 of their scale (median 2e-5) of the fp32 oracle evaluated with the same ReLU masks;
+    mask disagreements only at near-ties (see tests/decisions.py).  (64, 2, 64, 5) is the golden case of
+    test_train_step_matches_reference, whose loose band this test replaces."""
+    x, y = pkg.synthetic_batch(n, size, seed=seed)
+    D.check_step(pkg, oracle, base, n, seed, x, y, tol=1e-4, median_tol=2e-5)
+
+
+def test_eval_mode_backward_uses_the_running_statistics(pkg, oracle):
+    """model.eval(); loss.backward() (frozen-BN fine-tuning, saliency maps): BatchNorm is a per-channel affine map there, so dx has no
+    batch-statistics terms; gradients against the oracle's autograd with training=False."""
+    base, n, size, seed = 16, 2, 64, 3
+    x, y = pkg.synthetic_batch(n, size, seed=seed)
+    D.check_step(pkg, oracle, base, n, seed, x, y, tol=1e-4, median_tol=2e-5, training=False)

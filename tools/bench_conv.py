@@ -1,4 +1,4 @@
-#!/usr/bin/env python3
+
 """Per-layer micro-benchmark of the implicit-GEMM conv kernels (fwd / dgrad / wgrad) at the
 RobustUNet config-2 shapes (16 x 256 x 256).  Prints TFLOP/s against the 157.3 TF fp32-MFMA peak."""
 import importlib

@@ -1,4 +1,4 @@
-#!/usr/bin/env python3
+
 """DeepLabV3+ baseline (BASELINE.json config 4) train-step throughput on one MI355X: 256x256, batch 16, fp32, BCE + Adam.
 Not a bench line of the contract (bench.py measures the Robust U-Net metric); the figure is quoted in DESIGN.md."""
 import importlib

@@ -1,4 +1,4 @@
-#!/usr/bin/env python3
+
 """Micro-benchmark of the batched fp32 MFMA GEMM entry points at the F(4x4,3x3) position-GEMM shapes (batch 36)."""
 import importlib
 import os

@@ -1,4 +1,4 @@
-#!/usr/bin/env python3
+
 """Run one conv shape a few times (for rocprofv3 --pmc): conv_one.py cin cout spatial k mode[fwd|dgrad|wgrad] [iters]"""
 import importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,4 +1,4 @@
-#!/usr/bin/env python3
+
 """Does a single-rank RCCL all_reduce block the HOST until the waited-for streams catch up?  (diagnostic for ddp.GradAllReducer)"""
 import os
 import time

@@ -1,4 +1,4 @@
-#!/usr/bin/env python3
+
 """Per-kernel HBM traffic from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected separately, as
 MI355X_MICROARCH.md prescribes): pmc_traffic.py <fetch_dir> <write_dir> <out.json>.
 bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024  (gfx950: FETCH_SIZE reports half of a wide coalesced read)."""

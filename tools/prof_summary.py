@@ -1,4 +1,4 @@
-#!/usr/bin/env python3
+
 """Condense a rocprofv3 --kernel-trace --stats CSV directory into a per-kernel table (ms per step)."""
 import csv
 import glob

@@ -1,4 +1,4 @@
-#!/usr/bin/env python3
+
 """Convergence sanity of the full path (base 64, side streams, Winograd F(2x2)/F(4x4)): fit 8 fixed synthetic tiles for 150 steps."""
 import importlib
 import os
