@@ -89,6 +89,7 @@ class GradAllReducer:
                 for v in views:
                     v.copy_(flat[off:off + v.numel()])
                     off += v.numel()
+        _ops().bump_weight_epoch()       # written through .data views: the parameters' version counters did not move
 
     # -- per-step ----------------------------------------------------------------------------
     def _launch(self, lo, hi):

@@ -406,6 +406,7 @@ class RobustUNet(nn.Module):
         self.dec1 = ResidualBlock(b * 2, b, dropout_rate=0.1)
         self.outc = nn.Sequential(Conv2d(b, n_classes, 1), _Act())
         self.sync_bn_hook = None     # set by ddp.GradAllReducer(sync_bn=True)
+        self.precision = "f32"       # operand type of the convolutions' multiply-adds: set_precision("bf16") for BASELINE configs 3 / 5
         self._arena = None
         self._initialize_weights()
 
@@ -429,6 +430,14 @@ class RobustUNet(nn.Module):
             self._arena = GradArena(self)
         return self._arena
 
+    def set_precision(self, mode):
+        """'f32' (the reference's arithmetic) or 'bf16': convolution operands rounded to bf16, fp32 accumulation; parameters (fp32
+        masters), activations in HBM, BatchNorm, attention, loss and optimizer stay fp32 (ops.precision)."""
+        if mode not in ("f32", "bf16"):
+            raise ValueError("precision must be 'f32' or 'bf16'")
+        self.precision = mode
+        return self
+
     def set_dropout_masks(self, masks):
         """masks: {block prefix: [N, C] keep-mask already divided by 1-p} or None to restore random draws."""
         for k, rb in self._rbs().items():
@@ -448,6 +457,11 @@ class RobustUNet(nn.Module):
 
 
 def net_forward(net: RobustUNet, x, save, want_logit=False):
+    with ops.precision(net.precision):
+        return _net_forward(net, x, save, want_logit)
+
+
+def _net_forward(net: RobustUNet, x, save, want_logit=False):
     tr = net.training
     hook = net.sync_bn_hook if tr else None
     n = x.shape[0]
@@ -474,6 +488,7 @@ def net_forward(net: RobustUNet, x, save, want_logit=False):
     prob, logit = B.outc_forward(y, w, b, want_logit)
     if save:
         C["head"] = (y, w, prob)
+        C["precision"] = net.precision
     return prob, logit, (C if save else None)
 
 
@@ -533,7 +548,7 @@ class GradArena:
 
 def net_backward(C, dprob, sink, done=lambda blk: None):
     """Explicit backward pass; parameter gradients are written through `sink` (GradArena or DictSink)."""
-    with ops.wgrad_side_stream():
+    with ops.precision(C.get("precision", "f32")), ops.wgrad_side_stream():
         _net_backward(C, dprob, sink, done)
 
 

@@ -36,6 +36,89 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# ---- operand precision of the matrix-core kernels.  "f32": the reference's arithmetic (fp32 MFMA, Winograd forms included).
+# "bf16" (BASELINE.json configs 3 / 5): every convolution with >= 8 input channels rounds its two operands to bf16 on the way into LDS and
+# accumulates in fp32 (csrc/conv_bf16.hip); weights stay fp32 masters, activations / BatchNorm / attention / loss / Adam stay fp32.
+_PRECISION = "f32"
+
+
+class precision:
+    """with ops.precision("bf16"): ...   (model.RobustUNet.set_precision wraps forward and backward in it)"""
+
+    def __init__(self, mode):
+        if mode not in ("f32", "bf16"):
+            raise ValueError("precision must be 'f32' or 'bf16'")
+        self.mode = mode
+
+    def __enter__(self):
+        global _PRECISION
+        self.prev, _PRECISION = _PRECISION, self.mode
+        return self
+
+    def __exit__(self, *exc):
+        global _PRECISION
+        _PRECISION = self.prev
+        return False
+
+
+# ---- derived-weight cache: Winograd-domain filters (fp32 path) and packed bf16 weights are functions of the weights alone, and the
+# weights change once per optimizer step, so they are produced once per step instead of once per use (forward + data gradient of the same
+# layer, 36 + 24 transform launches per step).  FusedAdam updates parameters through raw pointers (no torch version bump), so it bumps
+# WEIGHT_EPOCH; torch-side writes (load_state_dict, optimizers from torch.optim) bump the tensor's _version.
+WEIGHT_EPOCH = 0
+_derived = {}
+
+
+def bump_weight_epoch():
+    global WEIGHT_EPOCH
+    WEIGHT_EPOCH += 1
+    if len(_derived) > 4096:
+        _derived.clear()
+
+
+def _cached(w, kind, make):
+    base = w._base if w._base is not None else w
+    key = (w.data_ptr(), kind)
+    tag = (base._version, WEIGHT_EPOCH, tuple(w.shape))
+    hit = _derived.get(key)
+    if hit is not None and hit[0] == tag:
+        return hit[1]
+    val = make()
+    _derived[key] = (tag, val)
+    return val
+
+
+def _bf16_case(cin, cin_w):
+    return _PRECISION == "bf16" and cin_w == cin and cin >= 8
+
+
+def bf16_weights(w_hwio, transpose=False):
+    """HWIO fp32 weight [kh, kw, cin, cout] -> packed bf16 [taps][K/8][N][8] (forward: K = cin; transpose: K = cout, data gradients)."""
+    kh, kw, cin, cout = w_hwio.shape
+
+    def make():
+        k, n = (cout, cin) if transpose else (cin, cout)
+        buf = torch.empty(lib.runet_bf16_pack_elems(kh * kw, k, n), device=w_hwio.device, dtype=torch.bfloat16)
+        check(lib.runet_bf16_pack_weights(w_hwio.data_ptr(), buf.data_ptr(), kh * kw, cin, cout, int(transpose), stream()))
+        return buf
+    return _cached(w_hwio, "bf16t" if transpose else "bf16", make)
+
+
+def _igemm_bf16(mode, x, w_hwio, bias, out, n, h, wd, cin, cout, kh, kw, dil, accumulate, transpose):
+    wp = bf16_weights(w_hwio, transpose)
+    prof = _PROFILE is not None
+    if prof:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(lib.runet_conv_igemm_bf16(x.data_ptr(), ld(x), wp.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(), ld(out),
+                                    n, h, wd, cin, cout, kh, kw, dil, mode, int(accumulate), stream()))
+    if prof:
+        e1.record()
+        fl = 2.0 * n * h * wd * (4 if kh == 2 else kh * kw) * cin * cout
+        _PROFILE.append(("igemm_bf16_kernel", fl, fl, e0, e1))
+    return out
+
+
 def ld(t):
     """Pixel stride of an NHWC view; validates the layout contract."""
     n, h, w, c = t.shape
@@ -134,6 +217,10 @@ def _wino4_case(h, w, kh, dil, k, n, cin_w):
 def conv_fwd(x, w_hwio, bias=None, out=None, dil=1, accumulate=False, keep_v=None):
     n, h, w, cin = x.shape
     kh, kw, cin_w, cout = w_hwio.shape
+    if _bf16_case(cin, cin_w):
+        if out is None:
+            out = empty_nhwc(n, h, w, cout, x)
+        return _igemm_bf16(CONV_FWD, x, w_hwio, bias, out, n, h, w, cin, cout, kh, kw, dil, accumulate, False)
     if _wino4_case(h, w, kh, dil, cin, cout, cin_w):
         return wino4_conv(x, wino4_weights(w_hwio), bias, out=out, accumulate=accumulate, keep_v=keep_v)
     if _wino_case(h, w, kh, dil, cin, cout, cin_w, n, ld(x), ld(out) if out is not None else cout):
@@ -149,9 +236,12 @@ def wino_weights(w_hwio, dgrad=False):
     """HWIO 3x3 weight -> Winograd-domain U[16][K][N] (forward: K=cin, N=cout; dgrad: rotated filter, K=cout, N=cin)."""
     _, _, cin, cout = w_hwio.shape
     k, n = (cout, cin) if dgrad else (cin, cout)
-    U = torch.empty((16, k, n), device=w_hwio.device, dtype=torch.float32)
-    check(lib.runet_wino_weights(w_hwio.data_ptr(), U.data_ptr(), cin, cout, int(dgrad), stream()))
-    return U
+
+    def make():
+        U = torch.empty((16, k, n), device=w_hwio.device, dtype=torch.float32)
+        check(lib.runet_wino_weights(w_hwio.data_ptr(), U.data_ptr(), cin, cout, int(dgrad), stream()))
+        return U
+    return _cached(w_hwio, "wino2d" if dgrad else "wino2", make)
 
 
 def wino_conv(x, U, bias=None, out=None, accumulate=False):
@@ -180,6 +270,10 @@ def conv_dgrad(dy, w_hwio, out=None, dil=1, accumulate=False):
     n, h, w, cout = dy.shape
     kh, kw, cin, cout_w = w_hwio.shape
     assert cout_w == cout
+    if _bf16_case(cout, cout):
+        if out is None:
+            out = empty_nhwc(n, h, w, cin, dy)
+        return _igemm_bf16(CONV_DGRAD, dy, w_hwio, None, out, n, h, w, cout, cin, kh, kw, dil, accumulate, True)
     if _wino4_case(h, w, kh, dil, cout, cin, cout):
         return wino4_conv(dy, wino4_weights(w_hwio, dgrad=True), None, out=out, accumulate=accumulate)
     if _wino_case(h, w, kh, dil, cout, cin, cout, n, ld(dy), ld(out) if out is not None else cin):
@@ -248,6 +342,8 @@ def _conv_wgrad(x, dy, kh, kw, cin_w=None, dil=1, out=None, v=None):
     cin_w = cin if cin_w is None else cin_w
     if out is None:
         out = torch.empty((kh, kw, cin_w, cout), device=x.device, dtype=torch.float32)
+    if _bf16_case(cin, cin_w):
+        return _wgrad_bf16(x, dy, out, n, h, w, cin, cout, kh, kw, dil, 0)
     if _wino4_case(h, w, kh, dil, cin, cout, cin_w) and cout >= 16:
         return wino4_wgrad(x, dy, out=out, v=v)
     prof = _PROFILE is not None
@@ -272,11 +368,29 @@ def _conv_wgrad(x, dy, kh, kw, cin_w=None, dil=1, out=None, v=None):
     return out
 
 
+def _wgrad_bf16(x, dy, out, n, h, w, cin, cout, kh, kw, dil, transposed):
+    prof = _PROFILE is not None
+    if prof:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    nws = lib.runet_conv_wgrad_bf16_workspace_floats(n, h, w, cin, cout, kh, kw, dil, transposed)
+    ws = workspace(nws, x.device)
+    check(lib.runet_conv_wgrad_bf16(x.data_ptr(), ld(x), dy.data_ptr(), ld(dy), out.data_ptr(), ws.data_ptr(), ws.numel(), n, h, w, cin, cout,
+                                    kh, kw, dil, transposed, stream()))
+    if prof:
+        e1.record()
+        fl = 2.0 * n * h * w * kh * kw * cin * cout
+        _PROFILE.append(("wgrad_bf16_kernel(+reduce)", fl, fl, e0, e1))
+    return out
+
+
 def convt_fwd(x, w_hwio, bias=None, out=None):
     n, h, w, cin = x.shape
     _, _, cin_w, cout = w_hwio.shape
     if out is None:
         out = empty_nhwc(n, 2 * h, 2 * w, cout, x)
+    if _bf16_case(cin, cin_w):
+        return _igemm_bf16(CONVT_FWD, x, w_hwio, bias, out, n, h, w, cin, cout, 2, 2, 1, False, False)
     _igemm(CONVT_FWD, x.data_ptr(), ld(x), w_hwio.data_ptr(), bias.data_ptr() if bias is not None else None,
            out.data_ptr(), ld(out), n, h, w, cin, cin_w, cout, 2, 2, 1, 0)
     return out
@@ -288,6 +402,8 @@ def convt_dgrad(dy, w_hwio, out=None, accumulate=False):
     h, w = h2 // 2, w2 // 2
     if out is None:
         out = empty_nhwc(n, h, w, cin, dy)
+    if _bf16_case(cout, cout):
+        return _igemm_bf16(CONVT_DGRAD, dy, w_hwio, None, out, n, h, w, cout, cin, 2, 2, 1, accumulate, True)
     _igemm(CONVT_DGRAD, dy.data_ptr(), ld(dy), w_hwio.data_ptr(), None, out.data_ptr(), ld(out), n, h, w,
            cout, cout, cin, 2, 2, 1, int(accumulate))
     return out
@@ -306,6 +422,8 @@ def _convt_wgrad(x, dy, out=None):
     cout = dy.shape[3]
     if out is None:
         out = torch.empty((2, 2, cin, cout), device=x.device, dtype=torch.float32)
+    if _bf16_case(cin, cin):
+        return _wgrad_bf16(x, dy, out, n, h, w, cin, cout, 2, 2, 1, 1)
     nws = lib.runet_conv_wgrad_workspace_floats(n, h, w, cin, cout, 2, 2)
     ws = workspace(nws, x.device)
     check(lib.runet_conv_wgrad(x.data_ptr(), ld(x), dy.data_ptr(), ld(dy), out.data_ptr(), ws.data_ptr(), ws.numel(),
@@ -476,9 +594,12 @@ def wino4_weights(w_hwio, dgrad=False):
     """HWIO 3x3 weight -> U[36][K][N] (forward: K=cin, N=cout; dgrad: rotated filter, K=cout, N=cin)."""
     _, _, cin, cout = w_hwio.shape
     k, n = (cout, cin) if dgrad else (cin, cout)
-    U = torch.empty((36, k, n), device=w_hwio.device, dtype=torch.float32)
-    check(lib.runet_wino4_weights(w_hwio.data_ptr(), U.data_ptr(), cin, cout, int(dgrad), stream()))
-    return U
+
+    def make():
+        U = torch.empty((36, k, n), device=w_hwio.device, dtype=torch.float32)
+        check(lib.runet_wino4_weights(w_hwio.data_ptr(), U.data_ptr(), cin, cout, int(dgrad), stream()))
+        return U
+    return _cached(w_hwio, "wino4d" if dgrad else "wino4", make)
 
 
 def wino4_conv(x, U, bias=None, out=None, accumulate=False, keep_v=None):

@@ -13,6 +13,7 @@ from __future__ import annotations
 import numpy as np
 import torch
 
+from . import ops
 from ._lib import check, lib
 
 
@@ -74,6 +75,7 @@ class FusedAdam(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None):
+        ops.bump_weight_epoch()      # derived weights (Winograd-domain filters, packed bf16 copies) are stale after this step
         loss = None
         if closure is not None:
             with torch.enable_grad():

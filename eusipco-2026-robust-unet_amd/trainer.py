@@ -64,6 +64,7 @@ class TrainStep:
         self.optimizer.sync_hyper()
         self._graph.replay()
         self.optimizer.advance_host_step()
+        ops.bump_weight_epoch()          # the replay updated the weights: cached derived weights (eager fallback steps) are stale
         return self._static[2].detach().clone()
 
 

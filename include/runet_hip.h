@@ -235,6 +235,23 @@ int runet_head3x3_bwd(const float* dprob, const float* prob, const float* x, int
                       float* dw_db, int n_img, int h, int w_, int c, void* stream);
 
 
+/* ---- bf16-operand convolutions (BASELINE.json configs 3 and 5: "bf16" / reduced precision; the reference itself is fp32 only, so the
+ *      oracle for this path is the fp32 step and the tolerance is stated in tests/test_gpu_bf16.py) ----
+ * Only the two operands of each convolution's multiply-adds are rounded to bf16 (round-to-nearest-even) on their way into LDS;
+ * accumulation, activations in HBM, master weights, BatchNorm, attention, loss and Adam stay fp32.
+ * runet_bf16_pack_weights: HWIO fp32 w[taps][cin][cout] -> packed bf16 [taps][K/8][N][8] (K padded to a multiple of 8 with zeros);
+ *   transpose == 0: K = cin, N = cout (forward, k2-s2 transposed forward);  transpose != 0: K = cout, N = cin (data gradients).
+ *   `packed` holds runet_bf16_pack_elems(taps, K, N) 16-bit elements.
+ * runet_conv_igemm_bf16: same modes / geometry as runet_conv_igemm (cin_w == cin), weights from runet_bf16_pack_weights.
+ * runet_conv_wgrad_bf16: same contract as runet_conv_wgrad (cin_w == cin; dil only for 3x3). */
+long runet_bf16_pack_elems(int taps, int k, int n);
+int runet_bf16_pack_weights(const float* w_hwio, void* packed, int taps, int cin, int cout, int transpose, void* stream);
+int runet_conv_igemm_bf16(const float* x, int ldx, const void* wpacked, const float* bias, float* y, int ldy, int n_img, int h, int w_,
+                          int cin, int cout, int kh, int kw, int dil, int mode, int accumulate, void* stream);
+long runet_conv_wgrad_bf16_workspace_floats(int n_img, int h, int w_, int cin, int cout, int kh, int kw, int dil, int transposed);
+int runet_conv_wgrad_bf16(const float* x, int ldx, const float* dy, int ldy, float* dw, float* workspace, long workspace_floats,
+                          int n_img, int h, int w_, int cin, int cout, int kh, int kw, int dil, int transposed, void* stream);
+
 /* ---- harness helpers (Main_Final.py:577-578,596-597,648-649: `F.interpolate(outputs, size=masks.shape[-2:], mode='bilinear',
  *      align_corners=False)` when the model output and the mask differ in size; :82-117 standalone attention modules) ----
  * runet_bilinear_fwd: y[planes, ho, wo] = bilinear resize of x[planes, h, w] with ATen's align_corners=False source index

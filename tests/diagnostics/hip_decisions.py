@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""GPU diagnostic: which discrete decisions (ReLU masks, spatial-attention channel maxima) of the HIP train step differ from the fp32
+"""GPU diagnostic: which discrete decisions (ReLU masks, pool winners, attention maxima) of the HIP train step differ from the fp32
 oracle's on the same inputs, how close to a tie each one is, and the gradient agreement per parameter tensor - against the plain
 oracle and against the oracle evaluated under the HIP step's own ReLU decisions (tests/decisions.py).
 
@@ -31,16 +31,34 @@ def compare(base, n, size, seed):
     model.load_state_dict(st)
     model = model.to(dev).train()
     model.set_dropout_masks(masks)
-    ctxs, prob, logit = D.hip_step(model, x, y, dev)
+    blocks = importlib.import_module(D.PKG_NAME + ".blocks")
+    real_cs, sums = blocks.chan_sum, []
+
+    def cs_spy(t, out):          # every bias gradient of the step: fp64 re-summation of the SAME device tensor the kernel summed
+        sums.append((tuple(t.shape), t.detach().double().sum((0, 1, 2)).cpu(), t.detach().double().abs().sum((0, 1, 2)).cpu(), out))
+        return real_cs(t, out)
+
+    blocks.chan_sum = cs_spy
+    try:
+        dec, prob, logit = D.hip_step(model, x, y, dev)
+    finally:
+        blocks.chan_sum = real_cs
+    for shape, s64, sabs, out in sums:
+        if shape[3] >= 32 and shape[1] >= 64:
+            print("   chan_sum over %s: kernel vs fp64 of its own input: max |err| / sum|terms| = %.2e" % (shape, float(((out.cpu().double() - s64).abs() / sabs).max())))
     g_plain, named, rp, rl = D.oracle_step(oracle, st, masks, x, y)
-    flips = D.differing_decisions(ctxs, named, masks)
+    flips = D.differing_decisions(dec, named, masks)
     print(f"base {base} n {n} size {size} seed {seed}: logit max err {float((logit - rl).abs().max()):.2e} (scale {float(rl.abs().max()):.1f}); "
           f"p==1 flips {int(((prob == 1) != (rp == 1)).sum())}; differing decisions: {len(flips)}")
     for f in flips[:20]:
-        print("   %-13s %-15s at %s: oracle value / margin %.3e (tensor scale %.2e)" % f)
-    g_forced, _, _, _ = D.oracle_step(oracle, st, masks, x, y, forced=D.forced_from_hip(ctxs, masks))
-    for label, g in (("plain oracle", g_plain), ("oracle under the HIP step's ReLU decisions", g_forced)):
-        rows = D.grad_errors(model, g)
+        print("   %-13s %-15s at %s: margin %.3e (tensor scale %.2e)" % f)
+    g_forced, named_f, _, _ = D.oracle_step(oracle, st, masks, x, y, forced=D.forced_from_hip(dec, masks))
+    for k, (ref64, sabs) in named_f["up_bias"].items():
+        hip = dict(model.named_parameters())[k].grad.cpu().double()
+        print("   %s: |hip - fp64 resum of oracle terms| / sum|terms| = %.2e;  |oracle fp32 - same| / sum|terms| = %.2e;  |sum| / sum|terms| = %.2e" % (
+            k, float(((hip - ref64).abs() / sabs).max()), float(((g_forced[k].double() - ref64).abs() / sabs).max()), float((ref64.abs() / sabs).max())))
+    for label, g, ub in (("plain oracle", g_plain, named["up_bias"]), ("oracle under the HIP step's decisions", g_forced, named_f["up_bias"])):
+        rows = D.grad_errors(model, g, ub)
         print("   gradient max err / scale vs %s: median %.2e; worst: %s" % (label, float(np.median([r[0] for r in rows])),
                                                                             ", ".join("%s %.1e" % (r[1], r[0]) for r in rows[:4])))
 

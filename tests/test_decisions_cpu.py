@@ -1,0 +1,45 @@
+"""CPU: the decision-forcing machinery of tests/decisions.py is itself correct - forcing the oracle's OWN decisions reproduces its
+gradients bit for bit (ReLU masks, pool winners, attention maxima, gate ReLU), and forcing a different winner changes them."""
+import torch
+
+import decisions as D
+
+
+def _own_decisions(named, n):
+    dec = {"gate": {}, "pool": {}, "sa": {}, "ca": {}, "act": {}}
+    for pre in D.RB:
+        relus = [e for e in named[pre] if e[0] == "relu"]
+        # stand-ins with the right sign pattern (forced_from_hip only looks at > 0)
+        dec["act"][pre] = dict(a1=relus[0][1].float(), out=relus[-1][1].float())
+        dec["sa"][pre] = [e for e in named[pre] if e[0] == "sa_max"][0][1][:, 0]
+        dec["ca"][pre] = [e for e in named[pre] if e[0] == "ca_max"][0][1]
+    dec["act"]["bottleneck.1"] = dict(out=[e for e in named["bottleneck.1"] if e[0] == "relu"][-1][1].float())
+    for g in D.GATES:
+        dec["gate"][g] = [e for e in named[g] if e[0] == "relu"][-1][1]
+    for lvl, e in enumerate(named["pool"], 1):
+        idx, vals = e[1], e[2]
+        w = vals.shape[3]
+        dec["pool"][lvl] = ((idx // w) % 2) * 2 + (idx % w) % 2
+    return dec
+
+
+def test_forcing_own_decisions_is_the_identity_and_a_flip_is_not(pkg, oracle):
+    base, n, size, seed = 16, 2, 32, 3
+    st = oracle.init_state(3, 1, base, seed=seed, perturb_bn=True)
+    masks = oracle.dropout_masks(n, base, seed=seed)
+    x, y = pkg.synthetic_batch(n, size, seed=seed)
+    g0, named, _, _ = D.oracle_step(oracle, st, masks, x, y)
+    dec = _own_decisions(named, n)
+    assert D.differing_decisions(dec, named, None) == []
+    g1, _, _, _ = D.oracle_step(oracle, st, masks, x, y, forced=D.forced_from_hip(dec, None))
+    assert max(float((g0[k] - g1[k]).abs().max()) for k in g0) == 0.0
+    for kind, key, pos in (("pool", 1, (0, 0, 0, 0)), ("sa", "dec1", (0, 0, 0)), ("ca", "dec4", (0, 0))):
+        d2 = {k: (dict(v) if isinstance(v, dict) else v) for k, v in dec.items()}
+        t = d2[kind][key].clone()
+        t[pos] = (t[pos] + 1) % (4 if kind == "pool" else 8)
+        d2[kind] = dict(d2[kind])
+        d2[kind][key] = t
+        flips = D.differing_decisions(d2, named, None)
+        assert len(flips) == 1 and flips[0][3] >= 0.0
+        g2, _, _, _ = D.oracle_step(oracle, st, masks, x, y, forced=D.forced_from_hip(d2, None))
+        assert max(float((g0[k] - g2[k]).abs().max()) for k in g0) > 0.0, kind

@@ -1,0 +1,163 @@
+"""GPU: the bf16-operand path (BASELINE.json configs 3 and 5).  The reference is fp32 only, so the oracle is the
+fp32 computation and the tolerances are STATED here:
+
+  * kernel level: a bf16-operand convolution must equal the fp32 convolution of the bf16-ROUNDED operands (same products, fp32
+    accumulation in another order) to 2e-4 of the output's scale - that pins layouts, tap geometry and the transposing LDS reads exactly;
+  * step level: one train step with bf16 convolutions against the fp32 oracle step.  Rounding both operands of every product to 8
+    significant bits gives a relative error of ~2^-8 per product, averaged down by the 576 .. 9216 terms of each output and carried
+    through 39 BatchNorm-renormalised layers.  Stated tolerances (measured values are printed by the test: logits off by 1.0-1.4 % of
+    their scale, loss by 0.1 %, the median gradient norm by 0.2-1 %):
+      logits within 2.5 % of the logit scale; probabilities within 0.15 (a pixel on the decision boundary moves by sigmoid'(z) * dz <= 0.25 * dz);
+      loss within 1 %; the whole gradient (all 173 tensors flattened) has cosine similarity >= 0.995 with the fp32 gradient; per-tensor
+      gradient norms: median within 2 %, every tensor within 50 % (the smallest tensors - channel-attention MLPs - carry the most noise);
+      per-image IoU / accuracy of the predicted masks within 0.01 of the fp32 step's.
+"""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _ops():
+    return importlib.import_module("eusipco-2026-robust-unet_amd.ops")
+
+
+def _r(t):
+    return t.bfloat16().float()
+
+
+def _close(a, b, name, tol=2e-4):
+    a, b = a.detach().cpu().double(), b.detach().double()
+    scale = float(b.abs().max()) + 1e-30
+    err = float((a - b).abs().max())
+    assert err <= tol * scale, f"{name}: max err {err:.3e} vs scale {scale:.3e}"
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout,k,dil", [(2, 32, 32, 64, 64, 3, 1), (1, 20, 24, 16, 48, 3, 1), (2, 8, 8, 128, 256, 3, 1), (2, 16, 16, 64, 32, 1, 1),
+                                                  (1, 8, 8, 256, 128, 1, 1), (2, 16, 16, 32, 32, 3, 2), (1, 16, 16, 64, 64, 3, 4), (3, 4, 4, 8, 12, 3, 1),
+                                                  (2, 64, 64, 64, 128, 3, 1)])
+def test_bf16_conv_fwd_dgrad_wgrad_equal_fp32_conv_of_rounded_operands(n, h, w, cin, cout, k, dil):
+    ops = _ops()
+    g = torch.Generator().manual_seed(n * 1000 + h + cin + cout + k + dil)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    b = torch.randn(cout, generator=g)
+    gy = torch.randn(n, cout, h, w, generator=g)
+    pad = dil * (k // 2)
+    xr, wr, gr = _r(x).requires_grad_(True), _r(wt).requires_grad_(True), _r(gy)
+    yr = F.conv2d(xr, wr, b, padding=pad, dilation=dil)
+    yr.backward(gr)                                       # reference data / weight gradients from rounded dy as well
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    wd = wt.permute(2, 3, 1, 0).contiguous().to(DEV)      # HWIO
+    gd = gy.permute(0, 2, 3, 1).contiguous().to(DEV)
+    with ops.precision("bf16"):
+        y = ops.conv_fwd(xd, wd, b.to(DEV), dil=dil)
+        dx = ops.conv_dgrad(gd, wd, dil=dil)
+        dw = ops.conv_wgrad(xd, gd, k, k, dil=dil, on_side=False)
+        # accumulate into a channel slice of a wider buffer
+        wide = torch.ones(n, h, w, cout + 8, device=DEV)
+        ops.conv_fwd(xd, wd, None, out=wide[..., 4:4 + cout], dil=dil, accumulate=True)
+    _close(y.permute(0, 3, 1, 2), yr, "y")
+    _close(dx.permute(0, 3, 1, 2), xr.grad, "dx")
+    _close(dw.permute(3, 2, 0, 1), wr.grad, "dw")
+    _close(wide[..., 4:4 + cout].permute(0, 3, 1, 2), yr - b.view(1, -1, 1, 1) + 1.0, "accumulate into slice")
+    assert float(wide[..., :4].min()) == 1.0 and float(wide[..., 4 + cout:].max()) == 1.0
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout", [(2, 8, 8, 64, 32), (1, 6, 10, 128, 64), (2, 16, 16, 256, 128)])
+def test_bf16_transposed_conv(n, h, w, cin, cout):
+    ops = _ops()
+    g = torch.Generator().manual_seed(h * 100 + cin)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cin, cout, 2, 2, generator=g) / (cin * 4) ** 0.5
+    b = torch.randn(cout, generator=g)
+    gy = torch.randn(n, cout, 2 * h, 2 * w, generator=g)
+    xr, wr, gr = _r(x).requires_grad_(True), _r(wt).requires_grad_(True), _r(gy)
+    yr = F.conv_transpose2d(xr, wr, b, stride=2)
+    yr.backward(gr)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    wd = wt.permute(2, 3, 0, 1).contiguous().to(DEV)      # [2, 2, cin, cout]
+    gd = gy.permute(0, 2, 3, 1).contiguous().to(DEV)
+    with ops.precision("bf16"):
+        y = ops.convt_fwd(xd, wd, b.to(DEV))
+        dx = ops.convt_dgrad(gd, wd)
+        dw = ops._convt_wgrad(xd, gd)
+    _close(y.permute(0, 3, 1, 2), yr, "convT y")
+    _close(dx.permute(0, 3, 1, 2), xr.grad, "convT dx")
+    _close(dw.permute(2, 3, 0, 1), wr.grad, "convT dw")
+
+
+def _bf16_step(pkg, oracle, base, n, size, seed):
+    st = oracle.init_state(3, 1, base, seed=seed, perturb_bn=True)
+    masks = oracle.dropout_masks(n, base, seed=seed)
+    x, y = pkg.synthetic_batch(n, size, seed=seed)
+    model = pkg.RobustUNet(3, 1, base)
+    model.load_state_dict(st)
+    model = model.to(DEV).train().set_precision("bf16")
+    model.set_dropout_masks(masks)
+    prob, logit = model(x.to(DEV), return_logits=True)
+    loss = pkg.bce_loss(prob, y.to(DEV))
+    loss.backward()
+    P = {k: v.clone() for k, v in st.items()}
+    names = oracle.param_names(3, 1, base)
+    for k in names:
+        P[k].requires_grad_(True)
+    rp, rl = oracle.forward(P, x, True, masks)
+    rloss = oracle.bce_mean(rp, y)
+    rloss.backward()
+    return model, P, names, (prob, logit, loss), (rp, rl, rloss), (x, y)
+
+
+@pytest.mark.parametrize("base,n,size,seed", [(16, 2, 64, 3), (64, 2, 64, 5), (64, 2, 256, 47)])
+def test_bf16_train_step_against_the_fp32_oracle(pkg, oracle, base, n, size, seed):
+    torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
+    model, P, names, (prob, logit, loss), (rp, rl, rloss), (x, y) = _bf16_step(pkg, oracle, base, n, size, seed)
+    lscale = float(rl.abs().max())
+    perr = float((prob.detach().cpu() - rp.detach()).abs().max())
+    lerr = float((logit.detach().cpu() - rl.detach()).abs().max())
+    g = torch.cat([p.grad.detach().cpu().double().reshape(-1) for p in model.parameters()])
+    r = torch.cat([P[k].grad.double().reshape(-1) for k in names])
+    cos = float((g @ r) / (g.norm() * r.norm()))
+    gn = np.array([p.grad.double().norm().item() for p in model.parameters()])
+    rn = np.array([P[k].grad.double().norm().item() for k in names])
+    rel = np.abs(gn - rn) / (rn + 1e-3 * rn.max())
+    ev = pkg.ModelEvaluator(torch.device(DEV))
+    dm = 0.0
+    for i in range(n):
+        a = ev.calculate_metrics(prob[i, 0].detach(), y[i, 0].to(DEV))
+        b = oracle.seg_metrics(rp[i, 0].detach(), y[i, 0])
+        dm = max(dm, abs(a["iou"] - b["iou"]), abs(a["accuracy"] - b["accuracy"]))
+    print(f"\nbf16 step base {base} {n}x{size}^2: prob err {perr:.2e}, logit err {lerr:.2e} (scale {lscale:.1f}), loss {float(loss):.5f} vs {float(rloss):.5f}, "
+          f"gradient cosine {cos:.5f}, grad-norm rel err max {rel.max():.2e} ({names[int(rel.argmax())]}) median {np.median(rel):.2e}, IoU/acc diff {dm:.4f}")
+    assert lerr <= 2.5e-2 * lscale and perr <= 0.15
+    assert abs(float(loss) - float(rloss)) <= 1e-2 * max(1.0, abs(float(rloss)))
+    assert cos >= 0.995
+    assert np.median(rel) <= 2e-2 and rel.max() <= 0.5, (names[int(rel.argmax())], gn[int(rel.argmax())], rn[int(rel.argmax())])
+    assert dm <= 1e-2
+
+
+def test_bf16_config3_and_config5_train_steps(pkg, oracle):
+    """4 x 512^2 (config 3's per-GPU shard) and 1 x 1024^2 (config 5's tile) through the bf16 path: finite, deterministic, and the fused
+    Adam step on fp32 master weights moves every parameter by ~lr."""
+    trainer = importlib.import_module("eusipco-2026-robust-unet_amd.trainer")
+    for n, size in ((4, 512), (1, 1024)):
+        res = []
+        for rep in range(2):
+            model = pkg.RobustUNet(3, 1, 64)
+            model.load_state_dict(oracle.init_state(3, 1, 64, seed=9, perturb_bn=True))
+            model = model.to(DEV).train().set_precision("bf16")
+            model.set_dropout_masks({k: v.to(DEV) for k, v in oracle.dropout_masks(n, 64, seed=9).items()})
+            step = trainer.TrainStep(model, lr=1e-4, weight_decay=1e-4)
+            x, y = pkg.synthetic_batch(n, size, seed=61)
+            losses = [float(step(x.to(DEV), y.to(DEV))) for _ in range(2)]
+            res.append((losses, [p.detach().clone() for p in model.parameters()]))
+            assert all(np.isfinite(l) for l in losses) and losses[1] != losses[0]
+            assert all(p.dtype == torch.float32 for p in model.parameters())        # fp32 master weights
+        assert res[0][0] == res[1][0]
+        for a, b in zip(res[0][1], res[1][1]):
+            assert torch.equal(a, b)

@@ -63,7 +63,7 @@ def test_train_step_matches_reference(pkg, oracle, tag):
             # -1.3e-7, dec1 bn1 (1,44,63,20): -1.2e-6, dec1 out (1,22,47,63): -7.7e-7 on tensors of scale 6-9) that the HIP step
             # takes the other way, exactly as the reference does to itself with oneDNN on / off (tests/diagnostics/decision_flips.py:
             # same median 6e-4..1.2e-3, same worst tensors).  The tight gradient check, free of that lottery, is
-            # test_gradients_match_oracle_under_the_same_relu_decisions below (1e-4 of scale); this one keeps the loose band.
+            # test_gradients_match_oracle_under_the_same_decisions below (1e-4 of scale); this one keeps the loose band.
             scale = float(np.abs(gref).max()) + 1e-7 * float(ref.max())
             err = np.abs(p.grad.cpu().numpy() - gref)
             assert err.max() <= 3e-2 * scale, (k, err.max(), scale)
@@ -175,8 +175,11 @@ def test_rectangular_and_minimum_sizes_against_the_oracle(pkg, oracle, n, h, w, 
     lg = rl.detach().numpy()
     np.testing.assert_allclose(logit.detach().cpu().numpy(), lg, rtol=1e-3, atol=1e-3 * max(1.0, float(np.abs(lg).max()) / 10))
     assert abs(float(loss.detach()) - float(rloss.detach())) <= 1e-3 * max(1.0, abs(float(rloss.detach())))
-    # gradients: decision-aware (near-tie ReLU flips forced into the oracle), 1e-4 of each tensor's scale instead of 3e-2 on norms
-    D.check_step(pkg, oracle, base, n, seed, x, y, tol=1e-4, median_tol=2e-5)
+    # gradients: decision-aware (near-tie decisions forced into the oracle), 1e-4 of each tensor's scale instead of 3e-2 on norms.  The
+    # 16x16 tile keeps the old band: its bottleneck BatchNorms normalise TWO values per channel (N=2, 1x1 pixels), xhat = +-1 and
+    # 1/sigma amplifies every rounding difference of the encoder by orders of magnitude on both sides
+    tight = h * w > 256
+    D.check_step(pkg, oracle, base, n, seed, x, y, tol=1e-4 if tight else 5e-2, median_tol=2e-5 if tight else 5e-3)
 
 
 def test_single_value_per_channel_in_training_raises_like_torch(pkg):
@@ -194,9 +197,9 @@ def test_single_value_per_channel_in_training_raises_like_torch(pkg):
 
 
 @pytest.mark.parametrize("base,n,size,seed", [(16, 2, 64, 3), (64, 2, 64, 5), (64, 2, 64, 12), (32, 3, 32, 21)])
-def test_gradients_match_oracle_under_the_same_relu_decisions(pkg, oracle, base, n, size, seed):
-    """All 173 gradient tensors within 1e-4 of their scale (median 2e-5) of the fp32 oracle evaluated with the same ReLU masks;
-    mask disagreements only at near-ties (see tests/decisions.py).  (64, 2, 64, 5) is the golden case of
+def test_gradients_match_oracle_under_the_same_decisions(pkg, oracle, base, n, size, seed):
+    """All 173 gradient tensors within 1e-4 of their scale (median 2e-5) of the fp32 oracle evaluated under the same discrete decisions
+    (ReLU masks, pool winners, attention maxima); decisions differ only at near-ties (see tests/decisions.py).  (64, 2, 64, 5) is the golden case of
     test_train_step_matches_reference, whose loose band this test replaces."""
     x, y = pkg.synthetic_batch(n, size, seed=seed)
     D.check_step(pkg, oracle, base, n, seed, x, y, tol=1e-4, median_tol=2e-5)
