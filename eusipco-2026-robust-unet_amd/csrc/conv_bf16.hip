@@ -253,6 +253,168 @@ void launch_bgemm(const BGemmArgs& a, int gz, hipStream_t st) {
     hipLaunchKernelGGL((igemm_bf16_kernel<BN, WM, WN>), grid, dim3(256), lds, st, a);
 }
 
+// -------------------------------------------------------------------------------------------------- 3x3 (dilation 1) forward / data gradient
+// The generic kernel above gathers its A rows per tap from global memory: nine shifted reads of the same pixels, served by L2.  At the
+// bf16 matrix rate that gather IS the bound (7-9 TB/s of L2 traffic for a 64 -> 64 layer at 16 x 256^2, 3.7x its HBM time).  This kernel
+// reads the input ONCE: a block owns a 16 x 16 output patch x 64 output channels, stages the 18 x 18 halo patch of a 64-channel chunk in
+// LDS (fp32 -> bf16 on the way) and runs all nine taps from it - a tap shift moves the fragment's LDS ROW, so every ds_read_b128 stays
+// aligned.  Weights stream through a double-buffered 8 KB LDS tile per tap.  Wave w owns patch rows 4w .. 4w+3 (64 pixels x 64 channels:
+// 2 x 2 MFMA tiles, 64 accumulator registers).
+struct C3Args {
+    const float* x; int ldx;
+    const __bf16* w;              // packed [9][K8][Ncols][8]
+    const float* bias;
+    float* y; int ldy;
+    int K, K8, Ncols;
+    int Nimg, H, W, tiles_h, tiles_w, nchunks_n;
+    int flip;                     // 1: data gradient (tap (r, s) reads the source at offset (1 - r, 1 - s))
+    int accumulate;
+};
+constexpr int PT = 16, HP = PT + 2;                 // patch edge, halo patch edge
+constexpr int HROWS = HP * HP;                      // 324 halo pixels
+
+__global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(C3Args g) {
+    extern __shared__ __attribute__((aligned(16))) __bf16 smem[];
+    __bf16* halo = smem;                            // [324][LDA]
+    __bf16* Bs = smem + HROWS * LDA;                // [2][8 octets][64][8]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int nb = blockIdx.x % g.nchunks_n;
+    const int patch = blockIdx.x / g.nchunks_n;
+    const int tx = patch % g.tiles_w;
+    const int t2 = patch / g.tiles_w;
+    const int ty = t2 % g.tiles_h, n = t2 / g.tiles_h;
+    const int h0 = ty * PT, w0 = tx * PT, n0 = nb * 64;
+    const long img = (long)n * g.H * g.W;
+    const long tap_stride = (long)g.K8 * g.Ncols * 8;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int aq = tid & 15, ar = tid >> 4;
+    const int KC = (g.K + BK - 1) / BK;
+    // Measured alternatives that were NOT faster (64 -> 64 @ 16 x 256^2: 0.208 ms as written): weight tiles fetched two steps ahead through a
+    // 3-slot ring (0.233), all 21 halo requests issued before the first conversion + all 16 fragment reads of a tap up front (0.225).
+    // rocprofv3 --pmc: 61 % of the wave time is s_waitcnt / barrier, MFMA busy ~15 %: with ~60 KB of LDS and 170 registers only two
+    // blocks share a CU, and a block requests its 83 KB halo only between two tap phases, so the bytes in flight per CU stay far below
+    // what HBM latency x bandwidth needs (next step: LDS-DMA prefetch of the NEXT patch's fp32 halo during the tap phase).
+    f32x4 rb[2];
+    auto load_b = [&](int kc, int tap) {
+        const __bf16* wt = g.w + (long)tap * tap_stride;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int id = tid + 256 * i;
+            const int oc = id >> 6, nn = id & 63;
+            const int ko = kc * 8 + oc;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ko < g.K8 && n0 + nn < g.Ncols) v = *reinterpret_cast<const f32x4*>(wt + ((long)ko * g.Ncols + n0 + nn) * 8);
+            rb[i] = v;
+        }
+    };
+    auto store_b = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(Bs + buf * 4096 + (tid + 256 * i) * 8) = rb[i];
+    };
+
+    for (int kc = 0; kc < KC; ++kc) {
+        __syncthreads();                            // every wave is done reading the previous chunk's halo and B tiles
+        load_b(kc, 0);
+        const int kofs = kc * BK + aq * 4;
+        const bool kok = kofs < g.K;
+        // halo patch: 324 rows x 16 quads, 21 passes of 16 rows; loads issued in groups of 7 so that 7 requests are in flight per thread
+#pragma unroll
+        for (int grp = 0; grp < 3; ++grp) {
+            f32x4 v[7];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                const int row = ar + 16 * (grp * 7 + j);
+                const int ry = row / HP, rx = row - ry * HP;
+                const int ih = h0 + ry - 1, iw = w0 + rx - 1;
+                f32x4 t = {0.f, 0.f, 0.f, 0.f};
+                if (row < HROWS && kok && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W)
+                    t = *reinterpret_cast<const f32x4*>(g.x + (img + (long)ih * g.W + iw) * g.ldx + kofs);
+                v[j] = t;
+            }
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                const int row = ar + 16 * (grp * 7 + j);
+                if (row < HROWS) {
+                    bf16x4 b;
+                    b[0] = (__bf16)v[j][0]; b[1] = (__bf16)v[j][1]; b[2] = (__bf16)v[j][2]; b[3] = (__bf16)v[j][3];
+                    *reinterpret_cast<bf16x4*>(halo + row * LDA + aq * 4) = b;
+                }
+            }
+        }
+        store_b(0);
+        __syncthreads();
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap < 8) load_b(kc, tap + 1);
+            const int r = tap / 3, s = tap - 3 * r;
+            const int dr = g.flip ? 2 - r : r, ds = g.flip ? 2 - s : s;
+            const __bf16* Bt = Bs + (tap & 1) * 4096;
+#pragma unroll
+            for (int s16 = 0; s16 < BK / 16; ++s16) {
+                bf16x8 af[2], bf[2];
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const int py = 4 * wid + 2 * a + (li >> 4), px = li & 15;
+                    af[a] = *reinterpret_cast<const bf16x8*>(halo + ((py + dr) * HP + px + ds) * LDA + s16 * 16 + lh * 8);
+                }
+#pragma unroll
+                for (int b = 0; b < 2; ++b) bf[b] = *reinterpret_cast<const bf16x8*>(Bt + ((2 * s16 + lh) * 64 + b * 32 + li) * 8);
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
+            }
+            if (tap < 8) {
+                store_b((tap + 1) & 1);
+                __syncthreads();
+            }
+        }
+    }
+
+    // ---- epilogue: row r of tile a = pixel (4*wid + 2a + (row >> 4), row & 15); col = n0 + b*32 + li
+    int ncol[2];
+    float bv[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        ncol[b] = n0 + b * 32 + li;
+        bv[b] = (g.bias != nullptr && ncol[b] < g.Ncols) ? g.bias[ncol[b]] : 0.f;
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            float* drow[8];
+            float old[8][2];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int rr = half * 8 + i;
+                const int row = (rr & 3) + 8 * (rr >> 2) + 4 * lh;
+                const int oh = h0 + 4 * wid + 2 * a + (row >> 4), ow = w0 + (row & 15);
+                drow[i] = (oh < g.H && ow < g.W) ? g.y + (img + (long)oh * g.W + ow) * g.ldy : nullptr;
+#pragma unroll
+                for (int b = 0; b < 2; ++b) old[i][b] = (g.accumulate && drow[i] && ncol[b] < g.Ncols) ? drow[i][ncol[b]] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (drow[i]) {
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        if (ncol[b] < g.Ncols) drow[i][ncol[b]] = acc[a][b][half * 8 + i] + bv[b] + old[i][b];
+                }
+            }
+        }
+    }
+}
+
 // -------------------------------------------------------------------------------------------------- weight gradient
 struct BWGradArgs {
     const float* x; int ldx;     // [Nimg, H*xs, W*xs... see below]
@@ -316,43 +478,61 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(BWGradArgs g) {
     const int q4 = (lane >> 2) & 3, kh8 = lane >> 5;     // tr-read address role of this lane: block row q4; k half (pixels 8*kh8 ..)
     const int Hy = g.dy_up ? 2 * g.H : g.H, Wy = g.dy_up ? 2 * g.W : g.W;
 
-    for (long t = t_begin; t < t_end; ++t) {
+    // register prefetch: the global loads of tile t+1 are in flight while tile t multiplies
+    f32x4 rx[XPASS], ry[YPASS];
+    auto issue_loads = [&](long t) {
         const int tw = (int)(t % g.tiles_w);
         const long t2 = t / g.tiles_w;
         const int th = (int)(t2 % g.tiles_h);
         const int n = (int)(t2 / g.tiles_h);
         const int h0 = th * WT_H, w0 = tw * WT_W;
-        __syncthreads();          // previous tile's fragments are in registers / consumed
-        // ---- stage the x tile (with halo) and the dy tile, fp32 -> bf16, zero outside the image / past the channel count
+#pragma unroll
+        for (int i = 0; i < XPASS; ++i) {
+            const int row = sr + 16 * i;
+            const int ry_ = row / XW, rx_ = row - ry_ * XW;
+            int ih = h0 + ry_ - HALO, iw = w0 + rx_ - HALO;
+            if (NT == 1 && !g.dy_up) { ih += (tr - g.KH / 2) * g.dil; iw += (ts - g.KW / 2) * g.dil; }
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (row < XROWS && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W && ci0 + sq * 4 < g.Ci)
+                v = *reinterpret_cast<const f32x4*>(g.x + (((long)n * g.H + ih) * g.W + iw) * g.ldx + ci0 + sq * 4);
+            rx[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < YPASS; ++i) {
+            const int row = sr + 16 * i;
+            const int ry_ = row / WT_W, rx_ = row - ry_ * WT_W;
+            int oh = h0 + ry_, ow = w0 + rx_;
+            const bool in = oh < g.H && ow < g.W;
+            if (g.dy_up) { oh = 2 * oh + tr; ow = 2 * ow + ts; }
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (in && co0 + sq * 4 < g.Co) v = *reinterpret_cast<const f32x4*>(g.dy + (((long)n * Hy + oh) * Wy + ow) * g.ldy + co0 + sq * 4);
+            ry[i] = v;
+        }
+    };
+    auto store_lds = [&]() {
 #pragma unroll
         for (int i = 0; i < XPASS; ++i) {
             const int row = sr + 16 * i;
             if (row < XROWS) {
-                const int ry = row / XW, rx = row - ry * XW;
-                int ih = h0 + ry - HALO, iw = w0 + rx - HALO;
-                if (NT == 1 && !g.dy_up) { ih += (tr - g.KH / 2) * g.dil; iw += (ts - g.KW / 2) * g.dil; }
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if ((unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W && ci0 + sq * 4 < g.Ci)
-                    v = *reinterpret_cast<const f32x4*>(g.x + (((long)n * g.H + ih) * g.W + iw) * g.ldx + ci0 + sq * 4);
                 bf16x4 b;
-                b[0] = (__bf16)v[0]; b[1] = (__bf16)v[1]; b[2] = (__bf16)v[2]; b[3] = (__bf16)v[3];
+                b[0] = (__bf16)rx[i][0]; b[1] = (__bf16)rx[i][1]; b[2] = (__bf16)rx[i][2]; b[3] = (__bf16)rx[i][3];
                 *reinterpret_cast<bf16x4*>(xs + row * WLD + sq * 4) = b;
             }
         }
 #pragma unroll
         for (int i = 0; i < YPASS; ++i) {
-            const int row = sr + 16 * i;
-            const int ry = row / WT_W, rx = row - ry * WT_W;
-            int oh = h0 + ry, ow = w0 + rx;
-            const bool in = oh < g.H && ow < g.W;
-            if (g.dy_up) { oh = 2 * oh + tr; ow = 2 * ow + ts; }
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (in && co0 + sq * 4 < g.Co) v = *reinterpret_cast<const f32x4*>(g.dy + (((long)n * Hy + oh) * Wy + ow) * g.ldy + co0 + sq * 4);
             bf16x4 b;
-            b[0] = (__bf16)v[0]; b[1] = (__bf16)v[1]; b[2] = (__bf16)v[2]; b[3] = (__bf16)v[3];
-            *reinterpret_cast<bf16x4*>(ys + row * WLD + sq * 4) = b;
+            b[0] = (__bf16)ry[i][0]; b[1] = (__bf16)ry[i][1]; b[2] = (__bf16)ry[i][2]; b[3] = (__bf16)ry[i][3];
+            *reinterpret_cast<bf16x4*>(ys + (sr + 16 * i) * WLD + sq * 4) = b;
         }
+    };
+
+    if (t_begin < t_end) issue_loads(t_begin);
+    for (long t = t_begin; t < t_end; ++t) {
+        __syncthreads();          // every wave has fetched the previous tile's fragments
+        store_lds();
         __syncthreads();
+        if (t + 1 < t_end) issue_loads(t + 1);
         // ---- 4 k-steps of 16 pixels (one tile row of 16 pixels each); B = dy fragments, shared by all taps
 #pragma unroll
         for (int ky = 0; ky < WT_H; ++ky) {
@@ -399,9 +579,9 @@ WPlan wgrad_bf16_plan(int n_img, int h, int w, int cin, int cout, int ntaps_grid
     p.tiles_h = cdiv(h, WT_H); p.tiles_w = cdiv(w, WT_W);
     p.total = (long)n_img * p.tiles_h * p.tiles_w;
     const long blocks = (long)cdiv(cin, 64) * cdiv(cout, 64) * ntaps_grid;
-    long want = (1024 + blocks - 1) / blocks;          // ~4 blocks per CU
+    long want = blocks >= 256 ? 1 : (512 + blocks - 1) / blocks;      // ~2 blocks per CU; enough (ci, co) tiles: no split at all
     if (want > p.total / 8) want = p.total / 8;         // at least 8 tiles (512 pixels) per split
-    if (want > 256) want = 256;
+    if (want > 512) want = 512;
     if (want < 1) want = 1;
     p.tps = (int)cdiv(p.total, want);
     p.splits = (int)cdiv(p.total, p.tps);
@@ -457,6 +637,17 @@ extern "C" int runet_conv_igemm_bf16(const float* x, int ldx, const void* wpacke
         RUNET_REQUIRE(false, "unknown mode");
     }
     hipStream_t st = (hipStream_t)stream;
+    if (kh == 3 && dil == 1 && (mode == RUNET_CONV_FWD || mode == RUNET_CONV_DGRAD)) {
+        C3Args c{};
+        c.x = x; c.ldx = ldx; c.w = (const __bf16*)wpacked; c.bias = bias; c.y = y; c.ldy = ldy; c.K = cin; c.K8 = (cin + 7) / 8; c.Ncols = cout;
+        c.Nimg = n_img; c.H = h; c.W = w_; c.tiles_h = cdiv(h, PT); c.tiles_w = cdiv(w_, PT); c.nchunks_n = cdiv(cout, 64);
+        c.flip = mode == RUNET_CONV_DGRAD ? 1 : 0; c.accumulate = accumulate;
+        const size_t lds = (HROWS * LDA + 2 * 4096) * sizeof(__bf16);
+        const long blocks = (long)n_img * c.tiles_h * c.tiles_w * c.nchunks_n;
+        RUNET_REQUIRE(blocks < (1L << 31), "grid too large");
+        hipLaunchKernelGGL(conv3x3_bf16_kernel, dim3((unsigned)blocks), dim3(256), lds, st, c);
+        RUNET_CHECK_LAUNCH();
+    }
     if (cout <= 32) launch_bgemm<32, 32, 32>(a, gz, st);
     else if (cout <= 64) launch_bgemm<64, 64, 32>(a, gz, st);
     else launch_bgemm<128, 64, 64>(a, gz, st);

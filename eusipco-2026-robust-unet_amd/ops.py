@@ -7,6 +7,7 @@ channel slice of a wider concat buffer).  All launches go to torch's current HIP
 from __future__ import annotations
 
 import os
+import weakref
 
 import torch
 
@@ -81,10 +82,11 @@ def _cached(w, kind, make):
     key = (w.data_ptr(), kind)
     tag = (base._version, WEIGHT_EPOCH, tuple(w.shape))
     hit = _derived.get(key)
-    if hit is not None and hit[0] == tag:
+    # the weak reference pins the entry to THIS parameter tensor: another model's weight allocated later at the same address misses
+    if hit is not None and hit[0] == tag and hit[2]() is base:
         return hit[1]
     val = make()
-    _derived[key] = (tag, val)
+    _derived[key] = (tag, val, weakref.ref(base))
     return val
 
 

@@ -12,11 +12,12 @@ N = int(os.environ.get("BENCH_N", 16))
 x = torch.randn((N, h, h, cin), device=dev)
 w = torch.randn((k, k, cin, cout), device=dev) * 0.05
 dy = torch.randn((N, h, h, cout), device=dev)
-for _ in range(iters):
-    if mode == "fwd":
-        ops.conv_fwd(x, w)
-    elif mode == "dgrad":
-        ops.conv_dgrad(dy, w)
-    else:
-        ops.conv_wgrad(x, dy, k, k)
+with ops.precision(os.environ.get("RUNET_PREC", "f32")):       # RUNET_PREC=bf16: the bf16-operand kernels
+    for _ in range(iters):
+        if mode == "fwd":
+            ops.conv_fwd(x, w)
+        elif mode == "dgrad":
+            ops.conv_dgrad(dy, w)
+        else:
+            ops.conv_wgrad(x, dy, k, k, on_side=False)
 torch.cuda.synchronize()
