@@ -5,7 +5,7 @@ The directory name carries the reference repository's name, so import it with
 
 Public surface (mirrors /root/reference/Main_Final.py for the hot path):
   RobustUNet, ResidualBlock, DilatedBlock, AttentionGate, ChannelAttention, SpatialAttention
-  CoastalDataset, prepare_dataset, ModelEvaluator
+  CoastalDataset, prepare_dataset, ModelEvaluator;  DeepLabV3Plus (baseline);  UNet (train_water_segmentation.py's 2-class model)
 plus the MI355X additions: FusedAdam, sigmoid-free fused BCE loss, GradAllReducer (RCCL).
 
 Sub-modules are imported lazily so that host-only pieces (data, portable_rng) stay usable
@@ -19,7 +19,7 @@ _LAZY = {
     "ChannelAttention": "model", "SpatialAttention": "model", "DeepLabV3Plus": "deeplab", "ASPP": "deeplab",
     "CoastalDataset": "data", "prepare_dataset": "data", "synthetic_batch": "data", "DevicePrefetcher": "data",
     "ModelEvaluator": "evaluator", "FusedAdam": "optim", "bce_loss": "ops", "GradAllReducer": "ddp",
-    "TrainStep": "trainer", "fit": "trainer",
+    "TrainStep": "trainer", "fit": "trainer", "UNet": "unet", "cross_entropy": "ops", "bilinear_resize": "ops",
 }
 
 

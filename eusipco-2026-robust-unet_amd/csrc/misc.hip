@@ -573,3 +573,106 @@ extern "C" int runet_mul_pixel(const float* x, int ldx, const float* s, float* y
     hipLaunchKernelGGL(mul_pixel_kernel, dim3(ew_grid(pixels * (c / 4))), dim3(TPB), 0, (hipStream_t)stream, x, ldx, s, y, ldy, pixels, c);
     RUNET_CHECK_LAUNCH();
 }
+
+// ============================================================================================================================
+// Plain 2-class U-Net head + loss of the reference's older trainer (/root/reference/train_water_segmentation.py:209-288 `UNet`,
+// :304 `nn.CrossEntropyLoss()`): logits leave the network as [N, classes, H, W]; the loss is the mean over all pixels of
+// logsumexp(z) - z[target] with ATen's log_softmax arithmetic (subtract the maximum first).
+namespace {
+__global__ __launch_bounds__(TPB) void nhwc_to_nchw_kernel(const float* __restrict__ x, int ld, float* __restrict__ y, int C, long HW, long total) {
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {      // i over [n][c][p]
+        const long p = i % HW;
+        const long t = i / HW;
+        const int c = (int)(t % C);
+        const long n = t / C;
+        y[i] = x[(n * HW + p) * ld + c];
+    }
+}
+constexpr int CE_MAXC = 8;
+// per block: partial sum of the per-pixel losses (double); the last kernel sums the partials in order
+__global__ __launch_bounds__(TPB) void ce_fwd_partial(const float* __restrict__ z, const long long* __restrict__ tgt, int C, long HW, long P,
+                                                      double* __restrict__ part) {
+    double acc = 0;
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < P; i += (long)gridDim.x * TPB) {
+        const long n = i / HW, p = i - n * HW;
+        const float* zp = z + n * C * HW + p;
+        float v[CE_MAXC], m = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < CE_MAXC; ++c) if (c < C) { v[c] = zp[(long)c * HW]; m = fmaxf(m, v[c]); }
+        float se = 0.f;
+#pragma unroll
+        for (int c = 0; c < CE_MAXC; ++c) if (c < C) se += expf(v[c] - m);
+        const float lse = logf(se);
+        const int t = (int)tgt[i];
+        float zt = 0.f;
+#pragma unroll
+        for (int c = 0; c < CE_MAXC; ++c) if (c == t) zt = v[c];
+        acc += (double)(-(zt - m - lse));
+    }
+    acc = wave_sum_d(acc);
+    __shared__ double red[TPB / 64];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0;
+        for (int k = 0; k < TPB / 64; ++k) s += red[k];
+        part[blockIdx.x] = s;
+    }
+}
+__global__ void ce_fwd_final(const double* __restrict__ part, int nparts, long P, float* __restrict__ loss) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0;
+        for (int k = 0; k < nparts; ++k) s += part[k];
+        *loss = (float)(s / (double)P);
+    }
+}
+__global__ __launch_bounds__(TPB) void ce_bwd_kernel(const float* __restrict__ z, const long long* __restrict__ tgt, const float* __restrict__ gout,
+                                                     float* __restrict__ dz, int C, long HW, long P) {
+    const float gs = gout[0] / (float)P;
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < P; i += (long)gridDim.x * TPB) {
+        const long n = i / HW, p = i - n * HW;
+        const float* zp = z + n * C * HW + p;
+        float* dp = dz + n * C * HW + p;
+        float v[CE_MAXC], m = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < CE_MAXC; ++c) if (c < C) { v[c] = zp[(long)c * HW]; m = fmaxf(m, v[c]); }
+        float se = 0.f;
+#pragma unroll
+        for (int c = 0; c < CE_MAXC; ++c) if (c < C) se += expf(v[c] - m);
+        const float lse = logf(se);
+        const int t = (int)tgt[i];
+#pragma unroll
+        for (int c = 0; c < CE_MAXC; ++c)
+            if (c < C) dp[(long)c * HW] = (expf(v[c] - m - lse) - (c == t ? 1.f : 0.f)) * gs;
+    }
+}
+}  // namespace
+
+extern "C" int runet_nhwc_to_nchw(const float* x, int ld, float* y, int n_img, int c, long hw, void* stream) {
+    RUNET_REQUIRE(x && y && n_img > 0 && c > 0 && hw > 0 && ld >= c, "bad arguments");
+    const long total = (long)n_img * c * hw;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(ew_grid(total)), dim3(TPB), 0, (hipStream_t)stream, x, ld, y, c, hw, total);
+    RUNET_CHECK_LAUNCH();
+}
+
+extern "C" int runet_ce_fwd(const float* logits_nchw, const long long* target, int n_img, int classes, long hw, double* partials1024, float* loss,
+                            void* stream) {
+    RUNET_REQUIRE(logits_nchw && target && partials1024 && loss && n_img > 0 && hw > 0, "bad arguments");
+    RUNET_REQUIRE(classes >= 2 && classes <= CE_MAXC, "2..8 classes");
+    const long P = (long)n_img * hw;
+    long b = (P + TPB * 4 - 1) / (TPB * 4);
+    if (b > 1024) b = 1024;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(ce_fwd_partial, dim3((int)b), dim3(TPB), 0, st, logits_nchw, target, classes, hw, P, partials1024);
+    hipLaunchKernelGGL(ce_fwd_final, dim3(1), dim3(64), 0, st, partials1024, (int)b, P, loss);
+    RUNET_CHECK_LAUNCH();
+}
+
+extern "C" int runet_ce_bwd(const float* logits_nchw, const long long* target, const float* gout, float* dlogits_nchw, int n_img, int classes, long hw,
+                            void* stream) {
+    RUNET_REQUIRE(logits_nchw && target && gout && dlogits_nchw && n_img > 0 && hw > 0, "bad arguments");
+    RUNET_REQUIRE(classes >= 2 && classes <= CE_MAXC, "2..8 classes");
+    const long P = (long)n_img * hw;
+    hipLaunchKernelGGL(ce_bwd_kernel, dim3(ew_grid(P)), dim3(TPB), 0, (hipStream_t)stream, logits_nchw, target, gout, dlogits_nchw, classes, hw, P);
+    RUNET_CHECK_LAUNCH();
+}

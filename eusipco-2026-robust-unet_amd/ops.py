@@ -464,6 +464,40 @@ def bce_loss(prob, target):
     return _BCELoss.apply(prob, target.to(torch.float32))
 
 
+class _CrossEntropy(torch.autograd.Function):
+    """nn.CrossEntropyLoss() (mean over all pixels) on [N, C, H, W] logits and int64 [N, H, W] targets
+    (/root/reference/train_water_segmentation.py:304)."""
+
+    @staticmethod
+    def forward(ctx, logits, target):
+        logits, target = logits.contiguous(), target.contiguous()
+        n, c, h, w = logits.shape
+        loss = torch.empty((), device=logits.device, dtype=torch.float32)
+        part = torch.empty(1024, device=logits.device, dtype=torch.float64)
+        check(lib.runet_ce_fwd(logits.data_ptr(), target.data_ptr(), n, c, h * w, part.data_ptr(), loss.data_ptr(), stream()))
+        ctx.save_for_backward(logits, target)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        logits, target = ctx.saved_tensors
+        n, c, h, w = logits.shape
+        dz = torch.empty_like(logits)
+        gout = gout.contiguous().to(torch.float32)
+        check(lib.runet_ce_bwd(logits.data_ptr(), target.data_ptr(), gout.data_ptr(), dz.data_ptr(), n, c, h * w, stream()))
+        return dz, None
+
+
+def cross_entropy(logits, target):
+    if not logits.is_cuda or logits.dtype != torch.float32 or logits.dim() != 4:
+        raise RuntimeError("cross_entropy takes float32 [N, C, H, W] logits on the HIP device")
+    if target.dtype != torch.int64 or tuple(target.shape) != (logits.shape[0], logits.shape[2], logits.shape[3]):
+        raise ValueError(f"target must be int64 [N, H, W], got {target.dtype} {tuple(target.shape)}")
+    if not 2 <= logits.shape[1] <= 8:
+        raise ValueError("2..8 classes")
+    return _CrossEntropy.apply(logits, target)
+
+
 class _Bilinear(torch.autograd.Function):
     """F.interpolate(x, size, mode='bilinear', align_corners=False) on [N, C, H, W] device tensors (the reference's harness resizes
     the model output to the mask size when they differ: /root/reference/Main_Final.py:577-578,596-597,648-649)."""

@@ -3,8 +3,26 @@ zero_grad -> forward -> BCE -> backward (-> RCCL all-reduce) -> Adam.  No host s
 (the reference's per-step `loss.item()` is left to the caller)."""
 from __future__ import annotations
 
+import torch
+
 from . import ops
 from .optim import FusedAdam
+
+
+def segmentation_loss(outputs, masks):
+    """The loss the reference pairs with each model: int64 class masks [N, H, W] -> CrossEntropyLoss on logits (plain U-Net,
+    train_water_segmentation.py:304); float masks [N, 1, H, W] -> BCELoss on probabilities, output resized to the mask if the sizes
+    differ (Main_Final.py:577-580)."""
+    if masks.dtype == torch.int64:
+        return ops.cross_entropy(outputs, masks)
+    return ops.bce_loss(ops.match_size(outputs, masks), masks)
+
+
+def _binary_maps(outputs, masks):
+    """(prediction, target) as float maps for the per-image metrics (threshold 0.5): class logits -> argmax == 1 (train_water_segmentation.py:384-388)."""
+    if masks.dtype == torch.int64:
+        return (outputs.argmax(dim=1) == 1).float(), (masks == 1).float()
+    return ops.match_size(outputs, masks), masks
 
 
 class TrainStep:
@@ -32,8 +50,7 @@ class TrainStep:
 
     def _body(self, images, masks):
         self.optimizer.zero_grad(set_to_none=True)
-        prob = ops.match_size(self.model(images), masks)
-        loss = ops.bce_loss(prob, masks)
+        loss = segmentation_loss(self.model(images), masks)
         loss.backward()
         if self.grad_sync is not None:
             self.grad_sync.finish()
@@ -43,7 +60,6 @@ class TrainStep:
     def __call__(self, images, masks):
         if not self.graph_mode:
             return self._body(images, masks)
-        import torch
         if self._graph is not None and (images.shape != self._static[0].shape or masks.shape != self._static[1].shape):
             return self._body(images, masks)          # ragged last batch: an ordinary step
         if self._eager_left > 0:
@@ -119,9 +135,9 @@ def fit(model, train_loader, val_loader, device, epochs=200, lr=1e-4, weight_dec
         vloss, mets = [], []
         with torch.no_grad():
             for images, masks in DevicePrefetcher(val_loader, device):
-                prob = ops.match_size(model(images), masks)
-                vloss.append(ops.bce_loss(prob, masks))
-                mets += ev.batch_metrics(prob, masks)
+                outputs = model(images)
+                vloss.append(segmentation_loss(outputs, masks))
+                mets += ev.batch_metrics(*_binary_maps(outputs, masks))
         val_loss = float(torch.stack(vloss).mean().item())
         iou, acc = float(np.mean([m["iou"] for m in mets])), float(np.mean([m["accuracy"] for m in mets]))
         if multi:       # every rank must see the same numbers: the LR schedule and the early stop are collective decisions

@@ -262,6 +262,16 @@ int runet_bilinear_fwd(const float* x, float* y, long planes, int h, int w, int 
 int runet_bilinear_bwd(const float* dy, float* dx, long planes, int h, int w, int ho, int wo, void* stream);
 int runet_mul_pixel(const float* x, int ldx, const float* s, float* y, int ldy, long pixels, int c, void* stream);
 
+/* ---- plain 2-class U-Net of the reference's older trainer (train_water_segmentation.py:209-288 `UNet`, :304 nn.CrossEntropyLoss;
+ *      consumer predict_coastline.py:351): built from the kernels above plus
+ * runet_nhwc_to_nchw: y[n][c][p] = x[(n*hw + p)*ld + c]  (the [N, classes, H, W] logits the module returns);
+ * runet_ce_fwd / runet_ce_bwd: mean cross-entropy over all pixels of NCHW logits (2..8 classes) against int64 targets [N, H, W],
+ *   ATen's log_softmax arithmetic; partials1024: 1024 doubles of scratch; gout: the scalar upstream gradient (device). */
+int runet_nhwc_to_nchw(const float* x, int ld, float* y, int n_img, int c, long hw, void* stream);
+int runet_ce_fwd(const float* logits_nchw, const long long* target, int n_img, int classes, long hw, double* partials1024, float* loss, void* stream);
+int runet_ce_bwd(const float* logits_nchw, const long long* target, const float* gout, float* dlogits_nchw, int n_img, int classes, long hw,
+                 void* stream);
+
 #ifdef __cplusplus
 }
 #endif

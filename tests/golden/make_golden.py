@@ -183,6 +183,53 @@ def deeplab_case(n, size, seed, tag):
                    "n_params": sum(p.numel() for p in model.parameters())}, f, indent=1)
 
 
+def unet_case(n, size, seed, tag):
+    """Plain 2-class U-Net + CrossEntropyLoss of the reference's older trainer (train_water_segmentation.py:209-288, :304): one train
+    step (Adam lr 1e-4 as :305) + eval forward through the reference class itself.  The file imports cv2 / osgeo.gdal / torchvision at
+    the top (none installed here, none touched by the model): empty stub modules stand in for them."""
+    for name in ("cv2", "osgeo", "osgeo.gdal"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["osgeo"].gdal = sys.modules["osgeo.gdal"]
+    tws = importlib.import_module("train_water_segmentation")
+    pu = importlib.import_module("oracle.plain_unet_ref")
+    out = {}
+    model = tws.UNet(n_channels=3, n_classes=2)
+    st = pu.init_state(3, 2, seed=seed, perturb_bn=True)
+    res = model.load_state_dict(st, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    x, y = pkg_data.synthetic_batch(n, size, seed=seed)
+    target = y[:, 0].long()
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    opt.zero_grad()
+    logits = model(x)
+    loss = torch.nn.CrossEntropyLoss()(logits, target)
+    loss.backward()
+    put(out, "logits", logits, full=True)
+    out["loss"] = np.array(loss.item(), dtype=np.float64)
+    names = [k for k, _ in model.named_parameters()]
+    out["grad_norm"] = np.array([p.grad.double().norm().item() for _, p in model.named_parameters()])
+    for k, p in model.named_parameters():
+        put(out, "grad/" + k, p.grad, full=p.numel() <= 4096)
+    for k, b in model.named_buffers():
+        if not k.endswith("num_batches_tracked"):
+            put(out, "buf/" + k, b, full=b.numel() <= 4096)
+    opt.step()
+    out["param_delta_abs_sum"] = np.array([(p.detach().double() - st[k].double()).abs().sum().item() for k, p in model.named_parameters()])
+    model.eval()
+    with torch.no_grad():
+        le = model(x)
+    put(out, "eval_logits", le, full=True)
+    pred = le.argmax(dim=1)
+    out["eval_accuracy"] = np.array((pred == target).float().mean().item())
+    np.savez_compressed(os.path.join(HERE, f"unet_{tag}.npz"), **out)
+    with open(os.path.join(HERE, f"unet_{tag}.json"), "w") as f:
+        json.dump({"n": n, "size": size, "seed": seed, "param_names": names,
+                   "state_dict": [[k, list(v.shape), str(v.dtype)] for k, v in model.state_dict().items()],
+                   "n_params": sum(p.numel() for p in model.parameters())}, f, indent=1)
+    print("unet", tag, "loss", loss.item(), "eval acc", float(out["eval_accuracy"]))
+
+
 def state_dict_case():
     model = ref.RobustUNet()
     sd = model.state_dict()
@@ -303,6 +350,10 @@ def labelme_cases():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "unet":
+        unet_case(n=2, size=32, seed=13, tag="n2_s32")
+        unet_case(n=2, size=64, seed=15, tag="n2_s64")
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "deeplab":
         deeplab_case(n=2, size=64, seed=7, tag="n2_s64")
         deeplab_case(n=2, size=128, seed=9, tag="n2_s128")
@@ -314,3 +365,5 @@ if __name__ == "__main__":
     model_case(base=64, n=2, size=64, seed=5, tag="b64_n2_s64")
     deeplab_case(n=2, size=64, seed=7, tag="n2_s64")
     deeplab_case(n=2, size=128, seed=9, tag="n2_s128")
+    unet_case(n=2, size=32, seed=13, tag="n2_s32")
+    unet_case(n=2, size=64, seed=15, tag="n2_s64")

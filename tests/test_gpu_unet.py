@@ -1,0 +1,105 @@
+"""GPU: the plain 2-class U-Net (/root/reference/train_water_segmentation.py:209-288, CrossEntropyLoss :304)
+on the HIP kernels against golden vectors from the reference class: logits, loss, every gradient, BatchNorm buffers, one Adam step,
+eval-mode logits; plus the checkpoint round trip `predict_coastline.py:351` relies on."""
+import importlib
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, load_npz, sampled
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _pu():
+    return importlib.import_module("oracle.plain_unet_ref")
+
+
+@pytest.mark.parametrize("tag", ["n2_s32", "n2_s64"])
+def test_plain_unet_train_step_matches_reference(pkg, tag):
+    pu = _pu()
+    meta = json.load(open(os.path.join(GOLDEN, f"unet_{tag}.json")))
+    gold = load_npz(f"unet_{tag}.npz")
+    st = pu.init_state(3, 2, seed=meta["seed"], perturb_bn=True)
+    net = pkg.UNet(3, 2)
+    res = net.load_state_dict(st, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    net = net.to(DEV).train()
+    x, y = pkg.synthetic_batch(meta["n"], meta["size"], seed=meta["seed"])
+    target = y[:, 0].long().to(DEV)
+    opt = pkg.FusedAdam(net.parameters(), lr=1e-4)
+    opt.zero_grad()
+    logits = net(x.to(DEV))
+    loss = pkg.cross_entropy(logits, target)
+    loss.backward()
+    lg = gold["logits"]
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), lg, rtol=0, atol=1e-3 * max(1.0, float(np.abs(lg).max())))
+    assert abs(loss.item() - float(gold["loss"])) <= 1e-4
+    names = meta["param_names"]
+    gn = np.array([p.grad.double().norm().item() for p in net.parameters()])
+    ref = gold["grad_norm"]
+    rel = np.abs(gn - ref) / (ref + 1e-3 * ref.max())
+    assert rel.max() < 2e-2, (names[int(rel.argmax())], gn[int(rel.argmax())], ref[int(rel.argmax())])
+    for k, p in net.named_parameters():
+        if k.endswith(".bias") and k.split(".")[-2] in ("0", "3"):
+            continue            # conv bias in front of a train-mode BatchNorm: analytically zero gradient, rounding noise on both sides
+        key = f"grad/{k}"
+        g = p.grad.detach().cpu()
+        if key in gold:
+            a, b = g.numpy(), gold[key]
+        else:
+            a, b = sampled(g, gold[key + "/meta"]), gold[key + "/sample"]
+        scale = float(np.abs(b).max()) + 1e-7 * float(ref.max())
+        assert np.abs(a - b).max() <= 5e-3 * scale, (k, np.abs(a - b).max(), scale)
+    for k, b in net.named_buffers():
+        if f"buf/{k}" in gold:
+            np.testing.assert_allclose(b.cpu().numpy(), gold[f"buf/{k}"], rtol=1e-3, atol=1e-4, err_msg=k)
+    opt.step()
+    delta = np.array([(p.detach().cpu().double() - st[k].double()).abs().sum().item() for k, p in net.named_parameters()])
+    np.testing.assert_allclose(delta, gold["param_delta_abs_sum"], rtol=2e-2, atol=1e-9)
+    net.eval()
+    with torch.no_grad():
+        le = net(x.to(DEV))
+    el = gold["eval_logits"]
+    np.testing.assert_allclose(le.cpu().numpy(), el, rtol=0, atol=1e-3 * max(1.0, float(np.abs(el).max())))
+    assert abs(float((le.argmax(dim=1) == target).float().mean()) - float(gold["eval_accuracy"])) <= 1e-3
+
+
+def test_fused_cross_entropy_equals_torch(pkg):
+    g = torch.Generator().manual_seed(3)
+    z = (torch.randn(3, 2, 24, 40, generator=g) * 4).requires_grad_(True)
+    t = (torch.rand(3, 24, 40, generator=g) > 0.4).long()
+    ref = torch.nn.functional.cross_entropy(z, t)
+    ref.backward()
+    zd = z.detach().to(DEV).requires_grad_(True)
+    loss = pkg.cross_entropy(zd, t.to(DEV))
+    loss.backward()
+    assert abs(loss.item() - ref.item()) <= 1e-6
+    np.testing.assert_allclose(zd.grad.cpu().numpy(), z.grad.numpy(), rtol=0, atol=1e-9)
+    with pytest.raises(ValueError):
+        pkg.cross_entropy(zd, t.float().to(DEV))
+
+
+def test_checkpoint_from_fit_loads_into_the_oracle_and_back(pkg, tmp_path):
+    """trainer.fit on the plain U-Net writes `best_water_segmentation_model.pth` with plain OIHW tensors under the reference's keys
+    (what predict_coastline.py:351 loads); the oracle evaluated on that checkpoint reproduces the device model's logits."""
+    trainer = importlib.import_module("eusipco-2026-robust-unet_amd.trainer")
+    pu = _pu()
+    torch.manual_seed(0)
+    net = pkg.UNet(3, 2).to(DEV)
+    xs, ys = pkg.synthetic_batch(6, 32, seed=21)
+    data = [(xs[i:i + 2], ys[i:i + 2, 0].long()) for i in range(0, 6, 2)]
+    hist = trainer.fit(net, data[:2], data[2:], torch.device(DEV), epochs=2, lr=1e-3, save_dir=str(tmp_path), log=lambda *_: None)
+    assert len(hist["train_losses"]) == 2 and all(np.isfinite(hist["val_losses"]))
+    ck = torch.load(os.path.join(tmp_path, "best_water_segmentation_model.pth"), weights_only=True)
+    assert all(v.is_contiguous() for v in ck.values())
+    net.load_state_dict(ck)
+    net.eval()
+    with torch.no_grad():
+        got = net(xs[:2].to(DEV)).cpu()
+    want = pu.forward({k: v.clone() for k, v in ck.items()}, xs[:2], training=False)
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=0, atol=1e-3 * max(1.0, float(want.abs().max())))
