@@ -726,11 +726,31 @@ void dispatch_igemm(const IGemmArgs& a, int gz, hipStream_t st) {
 
 }  // namespace
 
+namespace {
+// wt[tap][co][ci] = w[tap][ci][co]: 32x32 tiles through LDS, both sides coalesced
+__global__ __launch_bounds__(256) void transpose_taps_kernel(const float* __restrict__ w, float* __restrict__ wt, int cin, int cout) {
+    __shared__ float tile[32][33];
+    const long base = (long)blockIdx.z * cin * cout;
+    const int ci0 = blockIdx.y * 32, co0 = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8)
+        tile[r][tx] = (ci0 + r < cin && co0 + tx < cout) ? w[base + (long)(ci0 + r) * cout + co0 + tx] : 0.f;
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8)
+        if (co0 + r < cout && ci0 + tx < cin) wt[base + (long)(co0 + r) * cin + ci0 + tx] = tile[tx][r];
+}
+}  // namespace
+
+extern "C" int runet_transpose_taps(const float* w, float* wt, int taps, int cin, int cout, void* stream) {
+    RUNET_REQUIRE(w && wt && taps > 0 && cin > 0 && cout > 0, "bad arguments");
+    hipLaunchKernelGGL(transpose_taps_kernel, dim3(cdiv(cout, 32), cdiv(cin, 32), taps), dim3(256), 0, (hipStream_t)stream, w, wt, cin, cout);
+    RUNET_CHECK_LAUNCH();
+}
+
 extern "C" const char* runet_conv_igemm_kernel_name(int n_img, int h, int w_, int cout, int mode) {
     static const char* names[2][5] = {
         {"igemm_kernel<128, 32, 32, 32, false>", "igemm_kernel<256, 64, 64, 64, false>", "igemm_kernel<128, 64, 64, 32, false>", "igemm_kernel<128, 128, 64, 64, false>", "igemm_kernel<64, 64, 32, 32, false>"},
         {"igemm_kernel<128, 32, 32, 32, true>", "igemm_kernel<256, 64, 64, 64, true>", "igemm_kernel<128, 64, 64, 32, true>", "igemm_kernel<128, 128, 64, 64, true>", "igemm_kernel<64, 64, 32, 32, true>"}};
-    const bool kc = (mode == RUNET_CONV_DGRAD || mode == RUNET_CONVT_DGRAD);
+    const bool kc = (mode == RUNET_CONV_DGRAD || mode == RUNET_CONVT_DGRAD);      // the _T modes read pre-transposed weights with the n-contiguous kernels
     return names[kc ? 1 : 0][pick_variant((long)n_img * h * w_, cout)];
 }
 
@@ -771,6 +791,23 @@ extern "C" int runet_conv_igemm(const float* x, int ldx, const float* w, const f
         a.tdh = -dil; a.tdw = -dil; a.bh = dil * (kh / 2); a.bw = dil * (kw / 2);
         a.Hout = h; a.Wout = w_; a.o_scale = 1;
         dispatch_igemm<true>(a, gz, st);
+        break;
+    case RUNET_CONV_DGRAD_T:  // as RUNET_CONV_DGRAD with the weight already transposed per tap: w [kh,kw,cin(conv Cout),cout(conv Cin)]
+        RUNET_REQUIRE(kh != 2 && cin_w == cin, "dgrad reads every output channel; use RUNET_CONVT_DGRAD_T for 2x2");
+        a.K = (cin + 15) / 16 * 16; a.Kx = cin; a.Kvalid = cin; a.Ncols = cout;
+        a.w_tap_stride = (long)cout * cin; a.w_sk = cout; a.w_sn = 1;
+        a.H = h; a.W = w_; a.Hin = h; a.Win = w_; a.a_scale = 1;
+        a.tdh = -dil; a.tdw = -dil; a.bh = dil * (kh / 2); a.bw = dil * (kw / 2);
+        a.Hout = h; a.Wout = w_; a.o_scale = 1;
+        dispatch_igemm<false>(a, gz, st);
+        break;
+    case RUNET_CONVT_DGRAD_T: // as RUNET_CONVT_DGRAD with w [2,2,cin(convT Cout),cout(convT Cin)]
+        RUNET_REQUIRE(kh == 2 && kw == 2 && cin_w == cin, "transposed conv is 2x2 stride 2");
+        a.K = (cin + 15) / 16 * 16; a.Kx = cin; a.Kvalid = cin; a.Ncols = cout;
+        a.w_tap_stride = (long)cout * cin; a.w_sk = cout; a.w_sn = 1;
+        a.H = h; a.W = w_; a.Hin = 2 * h; a.Win = 2 * w_; a.a_scale = 2; a.tdh = 1; a.tdw = 1;
+        a.Hout = h; a.Wout = w_; a.o_scale = 1;
+        dispatch_igemm<false>(a, gz, st);
         break;
     case RUNET_CONVT_FWD:     // y[N,2h,2w,cout] = convT_k2s2(x[N,h,w,cin]); w [2,2,cin,cout]
         RUNET_REQUIRE(kh == 2 && kw == 2 && cin_w == cin, "transposed conv is 2x2 stride 2");

@@ -13,7 +13,7 @@ import torch
 
 from ._lib import check, lib
 
-CONV_FWD, CONV_DGRAD, CONVT_FWD, CONVT_DGRAD = 0, 1, 2, 3
+CONV_FWD, CONV_DGRAD, CONVT_FWD, CONVT_DGRAD, CONV_DGRAD_T, CONVT_DGRAD_T = 0, 1, 2, 3, 4, 5
 
 _ws = {}
 # Set by trainer.TrainStep once a step has been captured into a hipGraph: the graph holds the ADDRESSES of the scratch buffers, so a
@@ -88,6 +88,18 @@ def _cached(w, kind, make):
     val = make()
     _derived[key] = (tag, val, weakref.ref(base))
     return val
+
+
+def transposed_weights(w_hwio):
+    """[taps][cin][cout] -> [taps][cout][cin] (cached per optimizer step): the implicit-GEMM data gradients then stage their weight tile
+    n-contiguous like the forward kernels (49.7 -> ~75 TFLOP/s on the 1x1 / transposed / dilated data gradients)."""
+    kh, kw, cin, cout = w_hwio.shape
+
+    def make():
+        wt = torch.empty((kh, kw, cout, cin), device=w_hwio.device, dtype=torch.float32)
+        check(lib.runet_transpose_taps(w_hwio.data_ptr(), wt.data_ptr(), kh * kw, cin, cout, stream()))
+        return wt
+    return _cached(w_hwio, "T", make)
 
 
 def _bf16_case(cin, cin_w):
@@ -282,7 +294,7 @@ def conv_dgrad(dy, w_hwio, out=None, dil=1, accumulate=False):
         return wino_conv(dy, wino_weights(w_hwio, dgrad=True), None, out=out, accumulate=accumulate)
     if out is None:
         out = empty_nhwc(n, h, w, cin, dy)
-    _igemm(CONV_DGRAD, dy.data_ptr(), ld(dy), w_hwio.data_ptr(), None, out.data_ptr(), ld(out), n, h, w,
+    _igemm(CONV_DGRAD_T, dy.data_ptr(), ld(dy), transposed_weights(w_hwio).data_ptr(), None, out.data_ptr(), ld(out), n, h, w,
            cout, cout, cin, kh, kw, dil, int(accumulate))
     return out
 
@@ -406,7 +418,7 @@ def convt_dgrad(dy, w_hwio, out=None, accumulate=False):
         out = empty_nhwc(n, h, w, cin, dy)
     if _bf16_case(cout, cout):
         return _igemm_bf16(CONVT_DGRAD, dy, w_hwio, None, out, n, h, w, cout, cin, 2, 2, 1, accumulate, True)
-    _igemm(CONVT_DGRAD, dy.data_ptr(), ld(dy), w_hwio.data_ptr(), None, out.data_ptr(), ld(out), n, h, w,
+    _igemm(CONVT_DGRAD_T, dy.data_ptr(), ld(dy), transposed_weights(w_hwio).data_ptr(), None, out.data_ptr(), ld(out), n, h, w,
            cout, cout, cin, 2, 2, 1, int(accumulate))
     return out
 

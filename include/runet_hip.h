@@ -27,7 +27,7 @@ int runet_abi_version(void);
 
 /* ---- convolutions (Main_Final.py:157,159,172 ResidualBlock; :126,131 AttentionGate 1x1; :205-208
  *      DilatedBlock; :261-270 ConvTranspose2d k2 s2; autograd of the same via :581 loss.backward()) ---- */
-enum { RUNET_CONV_FWD = 0, RUNET_CONV_DGRAD = 1, RUNET_CONVT_FWD = 2, RUNET_CONVT_DGRAD = 3 };
+enum { RUNET_CONV_FWD = 0, RUNET_CONV_DGRAD = 1, RUNET_CONVT_FWD = 2, RUNET_CONVT_DGRAD = 3, RUNET_CONV_DGRAD_T = 4, RUNET_CONVT_DGRAD_T = 5 };
 
 /* mode FWD   : y[n,h,w,0:cout] (=|+=) bias + conv_{kh x kw, dilation dil, 'same' zero padding}(x[n,h,w,0:cin], w[kh,kw,cin_w,cout])
  *              cin is the channel count READ from x (multiple of 4, zero-padded by the caller);
@@ -36,10 +36,16 @@ enum { RUNET_CONV_FWD = 0, RUNET_CONV_DGRAD = 1, RUNET_CONVT_FWD = 2, RUNET_CONV
  *              w = the forward weight [kh,kw,cout,cin]; computes the data gradient.
  * mode CONVT_FWD  : y[n,2h,2w,0:cout] = bias + convT_{2x2,s2}(x[n,h,w,0:cin]),  w[2,2,cin,cout]
  * mode CONVT_DGRAD: x := dy[n,2h,2w,0:cin], y := dx[n,h,w,0:cout],  w[2,2,cout,cin]
+ * modes DGRAD_T / CONVT_DGRAD_T: the same data gradients with the weight already transposed per tap, w [taps][cin][cout] in THIS call's
+ *              naming (runet_transpose_taps of the forward weight, cached per optimizer step): the weight tile is then staged with the
+ *              n-contiguous loader of the forward kernels instead of the k-contiguous one (scalar LDS writes).
  * accumulate != 0 adds into y instead of overwriting.  bias may be NULL. */
 int runet_conv_igemm(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy,
                      int n_img, int h, int w_, int cin, int cin_w, int cout, int kh, int kw, int dil,
                      int mode, int accumulate, void* stream);
+
+/* wt[tap][co][ci] = w[tap][ci][co] */
+int runet_transpose_taps(const float* w, float* wt, int taps, int cin, int cout, void* stream);
 
 /* name of the kernel instantiation runet_conv_igemm launches for this shape (as rocprofv3 prints it, minus the
  * namespace), so that bench.py's live timings can be matched with the profiler's per-kernel rows */
