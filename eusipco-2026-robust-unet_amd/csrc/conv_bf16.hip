@@ -17,6 +17,7 @@
 //     its channel).  A block owns a 4 x 16 pixel tile of dy and the x tile WITH ITS HALO, and accumulates all taps from that one tile
 //     (tap shifts move whole LDS rows, so alignment is unaffected); fixed-order split-K slabs + slab reduce as in the fp32 path.
 #include "runet_common.h"
+#include <stdlib.h>
 #include "../../include/runet_hip.h"
 
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -270,12 +271,20 @@ struct C3Args {
     int flip;                     // 1: data gradient (tap (r, s) reads the source at offset (1 - r, 1 - s))
     int accumulate;
 };
-constexpr int PT = 16, HP = PT + 2;                 // patch edge, halo patch edge
-constexpr int HROWS = HP * HP;                      // 324 halo pixels
+constexpr int PT = 16, HP = PT + 2;                 // patch width, halo patch width
 
+// PH = patch height (16: 256 pixels per block, 2 blocks per CU; 8: 128 pixels, 3 blocks per CU).
+// Instruction count matters here: with no memory traffic and no MFMAs at all the first version of this kernel still took half its time
+// (timing ablations) - 2000+ address / predicate / exec-mask instructions per wave against 144 MFMAs.  Hence: halo row offsets
+// and validity are computed ONCE per block; interior patches (the vast majority) take branch-free load and store paths with 32-bit
+// offsets from per-block base pointers; LDS fragment addresses are one add per tap plus immediates.
+template <int PH>
 __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(C3Args g) {
+    constexpr int HROWS = (PH + 2) * HP;            // halo pixels
+    constexpr int TMA = PH / 8;                     // 32-pixel M-tiles per wave (wave w owns patch rows (PH/4)*w ..)
+    constexpr int HPASS = (HROWS + 15) / 16;        // halo staging passes (16 rows per pass: 16 threads cover the 64 channels of a row)
     extern __shared__ __attribute__((aligned(16))) __bf16 smem[];
-    __bf16* halo = smem;                            // [324][LDA]
+    __bf16* halo = smem;                            // [HROWS][LDA]
     __bf16* Bs = smem + HROWS * LDA;                // [2][8 octets][64][8]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
@@ -284,35 +293,52 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(C3Args g) {
     const int tx = patch % g.tiles_w;
     const int t2 = patch / g.tiles_w;
     const int ty = t2 % g.tiles_h, n = t2 / g.tiles_h;
-    const int h0 = ty * PT, w0 = tx * PT, n0 = nb * 64;
-    const long img = (long)n * g.H * g.W;
+    const int h0 = ty * PH, w0 = tx * PT, n0 = nb * 64;
     const long tap_stride = (long)g.K8 * g.Ncols * 8;
+    const int W = g.W, H = g.H;
 
-    f32x16 acc[2][2];
+    f32x16 acc[TMA][2];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < TMA; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+    // ---- halo staging plan, once per block: element offset of each of this thread's rows inside the image, validity bit mask
     const int aq = tid & 15, ar = tid >> 4;
+    const float* xb = g.x + (long)n * H * W * g.ldx + aq * 4;
+    int roff[HPASS];
+    unsigned rmask = 0;
+#pragma unroll
+    for (int j = 0; j < HPASS; ++j) {
+        const int row = ar + 16 * j;
+        const int ry = row / HP, rx = row - ry * HP;
+        const int ih = h0 + ry - 1, iw = w0 + rx - 1;
+        const bool ok = row < HROWS && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+        roff[j] = ok ? (ih * W + iw) * g.ldx : 0;
+        rmask |= (ok ? 1u : 0u) << j;
+    }
+    const bool interior = h0 >= 1 && w0 >= 1 && h0 + PH + 1 <= H && w0 + PT + 1 <= W;      // block-uniform: every halo pixel inside the image
+
+    // ---- LDS fragment bases (bytes), once per block
+    int a_base[TMA];
+#pragma unroll
+    for (int a = 0; a < TMA; ++a) a_base[a] = ((((PH / 4) * wid + 2 * a + (li >> 4)) * HP + (li & 15)) * LDA + lh * 8) * 2;
+    const int b_base = ((lh * 64 + li) * 8) * 2;
+    const char* halo_c = reinterpret_cast<const char*>(halo);
+    const char* Bs_c = reinterpret_cast<const char*>(Bs);
+
     const int KC = (g.K + BK - 1) / BK;
-    // Measured alternatives that were NOT faster (64 -> 64 @ 16 x 256^2: 0.208 ms as written): weight tiles fetched two steps ahead through a
-    // 3-slot ring (0.233), all 21 halo requests issued before the first conversion + all 16 fragment reads of a tap up front (0.225).
-    // rocprofv3 --pmc: 61 % of the wave time is s_waitcnt / barrier, MFMA busy ~15 %: with ~60 KB of LDS and 170 registers only two
-    // blocks share a CU, and a block requests its 83 KB halo only between two tap phases, so the bytes in flight per CU stay far below
-    // what HBM latency x bandwidth needs (next step: LDS-DMA prefetch of the NEXT patch's fp32 halo during the tap phase).
+    const bool n_full = n0 + 64 <= g.Ncols;
     f32x4 rb[2];
+    const int b_oc = tid >> 6, b_nn = tid & 63;       // weight unit (octet, column) of this thread; second unit: octet + 4
     auto load_b = [&](int kc, int tap) {
-        const __bf16* wt = g.w + (long)tap * tap_stride;
+        const __bf16* wt = g.w + (long)tap * tap_stride + ((long)(kc * 8 + b_oc) * g.Ncols + n0 + b_nn) * 8;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int id = tid + 256 * i;
-            const int oc = id >> 6, nn = id & 63;
-            const int ko = kc * 8 + oc;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ko < g.K8 && n0 + nn < g.Ncols) v = *reinterpret_cast<const f32x4*>(wt + ((long)ko * g.Ncols + n0 + nn) * 8);
+            if (kc * 8 + b_oc + 4 * i < g.K8 && (n_full || n0 + b_nn < g.Ncols)) v = *reinterpret_cast<const f32x4*>(wt + (long)4 * i * g.Ncols * 8);
             rb[i] = v;
         }
     };
@@ -324,29 +350,43 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(C3Args g) {
     for (int kc = 0; kc < KC; ++kc) {
         __syncthreads();                            // every wave is done reading the previous chunk's halo and B tiles
         load_b(kc, 0);
-        const int kofs = kc * BK + aq * 4;
-        const bool kok = kofs < g.K;
-        // halo patch: 324 rows x 16 quads, 21 passes of 16 rows; loads issued in groups of 7 so that 7 requests are in flight per thread
+        const int kofs = kc * BK;
+        const bool kfull = kofs + BK <= g.K;        // block-uniform
+        const bool kok = kofs + aq * 4 < g.K;
+        const float* xk = xb + kofs;
 #pragma unroll
         for (int grp = 0; grp < 3; ++grp) {
-            f32x4 v[7];
+            constexpr int HG = (HPASS + 2) / 3;
+            f32x4 v[HG];
+            if (interior && kfull) {                // branch-free: every row of every pass but (possibly) the last is a halo pixel inside the image
 #pragma unroll
-            for (int j = 0; j < 7; ++j) {
-                const int row = ar + 16 * (grp * 7 + j);
-                const int ry = row / HP, rx = row - ry * HP;
-                const int ih = h0 + ry - 1, iw = w0 + rx - 1;
-                f32x4 t = {0.f, 0.f, 0.f, 0.f};
-                if (row < HROWS && kok && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W)
-                    t = *reinterpret_cast<const f32x4*>(g.x + (img + (long)ih * g.W + iw) * g.ldx + kofs);
-                v[j] = t;
+                for (int j = 0; j < HG; ++j) {
+                    const int jj = grp * HG + j;
+                    if (jj < HPASS) {
+                        if ((jj + 1) * 16 <= HROWS) v[j] = *reinterpret_cast<const f32x4*>(xk + roff[jj]);
+                        else {
+                            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+                            if (ar + 16 * jj < HROWS) t = *reinterpret_cast<const f32x4*>(xk + roff[jj]);
+                            v[j] = t;
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < HG; ++j) {
+                    const int jj = grp * HG + j;
+                    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+                    if (jj < HPASS && ((rmask >> jj) & 1u) && kok) t = *reinterpret_cast<const f32x4*>(xk + roff[jj]);
+                    v[j] = t;
+                }
             }
 #pragma unroll
-            for (int j = 0; j < 7; ++j) {
-                const int row = ar + 16 * (grp * 7 + j);
-                if (row < HROWS) {
+            for (int j = 0; j < HG; ++j) {
+                const int jj = grp * HG + j;
+                if (jj < HPASS && (((jj + 1) * 16 <= HROWS) || ar + 16 * jj < HROWS)) {
                     bf16x4 b;
                     b[0] = (__bf16)v[j][0]; b[1] = (__bf16)v[j][1]; b[2] = (__bf16)v[j][2]; b[3] = (__bf16)v[j][3];
-                    *reinterpret_cast<bf16x4*>(halo + row * LDA + aq * 4) = b;
+                    *reinterpret_cast<bf16x4*>(halo + (ar + 16 * jj) * LDA + aq * 4) = b;
                 }
             }
         }
@@ -357,19 +397,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(C3Args g) {
             if (tap < 8) load_b(kc, tap + 1);
             const int r = tap / 3, s = tap - 3 * r;
             const int dr = g.flip ? 2 - r : r, ds = g.flip ? 2 - s : s;
-            const __bf16* Bt = Bs + (tap & 1) * 4096;
+            const int a_tap = (dr * HP + ds) * LDA * 2;                       // scalar byte offset of this tap's shifted halo window
+            const char* Bt = Bs_c + (tap & 1) * 8192 + b_base;
 #pragma unroll
             for (int s16 = 0; s16 < BK / 16; ++s16) {
-                bf16x8 af[2], bf[2];
+                bf16x8 af[TMA], bf[2];
 #pragma unroll
-                for (int a = 0; a < 2; ++a) {
-                    const int py = 4 * wid + 2 * a + (li >> 4), px = li & 15;
-                    af[a] = *reinterpret_cast<const bf16x8*>(halo + ((py + dr) * HP + px + ds) * LDA + s16 * 16 + lh * 8);
-                }
+                for (int a = 0; a < TMA; ++a) af[a] = *reinterpret_cast<const bf16x8*>(halo_c + a_base[a] + a_tap + s16 * 32);
 #pragma unroll
-                for (int b = 0; b < 2; ++b) bf[b] = *reinterpret_cast<const bf16x8*>(Bt + ((2 * s16 + lh) * 64 + b * 32 + li) * 8);
+                for (int b = 0; b < 2; ++b) bf[b] = *reinterpret_cast<const bf16x8*>(Bt + s16 * 2048 + b * 512);
 #pragma unroll
-                for (int a = 0; a < 2; ++a)
+                for (int a = 0; a < TMA; ++a)
 #pragma unroll
                     for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
             }
@@ -380,38 +418,40 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(C3Args g) {
         }
     }
 
-    // ---- epilogue: row r of tile a = pixel (4*wid + 2a + (row >> 4), row & 15); col = n0 + b*32 + li
-    int ncol[2];
+    // ---- epilogue.  Register rr of tile a: pixel (dy, dx) = ((PH/4)*wid + 2a + (rr >> 3), 8*((rr >> 2) & 1) + 4*lh + (rr & 3)); column n0 + b*32 + li
+    const int oy0 = h0 + (PH / 4) * wid;
+    float* yb = g.y + ((long)n * H * W + (long)oy0 * W + w0) * g.ldy + n0 + li;      // 64-bit once; everything below is a 32-bit offset from it
+    const int ldy = g.ldy;
+    const bool fast = h0 + PH <= H && w0 + PT <= W && n_full && !g.accumulate;        // block-uniform
     float bv[2];
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        ncol[b] = n0 + b * 32 + li;
-        bv[b] = (g.bias != nullptr && ncol[b] < g.Ncols) ? g.bias[ncol[b]] : 0.f;
-    }
+    for (int b = 0; b < 2; ++b) bv[b] = (g.bias != nullptr && n0 + b * 32 + li < g.Ncols) ? g.bias[n0 + b * 32 + li] : 0.f;
+    if (fast) {
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
+        for (int a = 0; a < TMA; ++a)
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            float* drow[8];
-            float old[8][2];
+            for (int rr = 0; rr < 16; ++rr) {
+                const int off = ((2 * a + (rr >> 3)) * W + 8 * ((rr >> 2) & 1) + 4 * lh + (rr & 3)) * ldy;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int rr = half * 8 + i;
-                const int row = (rr & 3) + 8 * (rr >> 2) + 4 * lh;
-                const int oh = h0 + 4 * wid + 2 * a + (row >> 4), ow = w0 + (row & 15);
-                drow[i] = (oh < g.H && ow < g.W) ? g.y + (img + (long)oh * g.W + ow) * g.ldy : nullptr;
-#pragma unroll
-                for (int b = 0; b < 2; ++b) old[i][b] = (g.accumulate && drow[i] && ncol[b] < g.Ncols) ? drow[i][ncol[b]] : 0.f;
+                for (int b = 0; b < 2; ++b) yb[off + b * 32] = acc[a][b][rr] + bv[b];
             }
+    } else {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                if (drow[i]) {
+        for (int a = 0; a < TMA; ++a)
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+                const int dy = 2 * a + (rr >> 3), dx = 8 * ((rr >> 2) & 1) + 4 * lh + (rr & 3);
+                if (oy0 + dy < H && w0 + dx < W) {
+                    const int off = (dy * W + dx) * ldy;
 #pragma unroll
                     for (int b = 0; b < 2; ++b)
-                        if (ncol[b] < g.Ncols) drow[i][ncol[b]] = acc[a][b][half * 8 + i] + bv[b] + old[i][b];
+                        if (n0 + b * 32 + li < g.Ncols) {
+                            float val = acc[a][b][rr] + bv[b];
+                            if (g.accumulate) val += yb[off + b * 32];
+                            yb[off + b * 32] = val;
+                        }
                 }
             }
-        }
     }
 }
 
@@ -432,6 +472,10 @@ struct BWGradArgs {
 constexpr int WT_H = 4, WT_W = 16;        // pixel tile
 constexpr int WLD = 64 + 8;               // bf16 per LDS row ([pixel][64 channels + pad]); 144 B keeps every tr-read address 8-byte aligned
 
+// Measured and NOT adopted (64 -> 64 @ 16 x 256^2: 0.335 ms as written): per-block precomputed staging offsets + branch-free interior path +
+// immediate-offset transposing reads (0.377 ms) - unlike the forward kernel this one is not bound by its instruction count but by LDS:
+// a 32 x 32 wave tile with nine taps reads ~1.1 KB of fragments per MFMA (rocprofv3: SQ_LDS_BANK_CONFLICT = 40 % of SQ_LDS_IDX_ACTIVE on
+// the transposing reads, MFMA busy 10 %).  Next step: 64-row wave tiles per tap group and a conflict-free (XOR-swizzled) tile image.
 // transposing fragment read: lane l of the wave gets, for the 32 channels c0 .. c0+31 (its channel = c0 + (l & 31)) and the 8 pixels
 // rows[0..7] (LDS row index of k = 8*(l>>5) + j given by the caller through `row_of`), the 8 values [pixel j][channel].
 // ds_read_b64_tr_b16: per 16-lane group, lane 4q+p supplies the address of block row q, columns 4p..4p+3; lane i receives column i of the 4 rows.
@@ -640,12 +684,18 @@ extern "C" int runet_conv_igemm_bf16(const float* x, int ldx, const void* wpacke
     if (kh == 3 && dil == 1 && (mode == RUNET_CONV_FWD || mode == RUNET_CONV_DGRAD)) {
         C3Args c{};
         c.x = x; c.ldx = ldx; c.w = (const __bf16*)wpacked; c.bias = bias; c.y = y; c.ldy = ldy; c.K = cin; c.K8 = (cin + 7) / 8; c.Ncols = cout;
-        c.Nimg = n_img; c.H = h; c.W = w_; c.tiles_h = cdiv(h, PT); c.tiles_w = cdiv(w_, PT); c.nchunks_n = cdiv(cout, 64);
+        // patch height 16 unless that leaves fewer than two blocks per CU (the deepest levels): then 8 doubles the block count
+        // (measured: 1024 -> 1024 @ 16 x 16^2 0.119 -> 0.105 ms; everywhere else 16 is 5-25 % faster).  RUNET_C3_PH=8|16 overrides.
+        static const int force_ph = getenv("RUNET_C3_PH") ? atoi(getenv("RUNET_C3_PH")) : 0;
+        const long blocks16 = (long)n_img * cdiv(h, 16) * cdiv(w_, PT) * cdiv(cout, 64);
+        const int ph = force_ph ? force_ph : (blocks16 < 512 ? 8 : 16);
+        c.Nimg = n_img; c.H = h; c.W = w_; c.tiles_h = cdiv(h, ph); c.tiles_w = cdiv(w_, PT); c.nchunks_n = cdiv(cout, 64);
         c.flip = mode == RUNET_CONV_DGRAD ? 1 : 0; c.accumulate = accumulate;
-        const size_t lds = (HROWS * LDA + 2 * 4096) * sizeof(__bf16);
+        const size_t lds = ((ph + 2) * HP * LDA + 2 * 4096) * sizeof(__bf16);
         const long blocks = (long)n_img * c.tiles_h * c.tiles_w * c.nchunks_n;
         RUNET_REQUIRE(blocks < (1L << 31), "grid too large");
-        hipLaunchKernelGGL(conv3x3_bf16_kernel, dim3((unsigned)blocks), dim3(256), lds, st, c);
+        if (ph == 8) hipLaunchKernelGGL(conv3x3_bf16_kernel<8>, dim3((unsigned)blocks), dim3(256), lds, st, c);
+        else hipLaunchKernelGGL(conv3x3_bf16_kernel<16>, dim3((unsigned)blocks), dim3(256), lds, st, c);
         RUNET_CHECK_LAUNCH();
     }
     if (cout <= 32) launch_bgemm<32, 32, 32>(a, gz, st);
