@@ -608,13 +608,22 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(BWGradArgs g) {
     }
 }
 
-// out[i] = sum_k slabs[k][i] in a fixed order (same scheme as the fp32 path's slab_reduce_kernel)
+// out[i] = sum_k slabs[k][i]: block = 32 float4 columns x 8 split-lanes, partial sums combined through LDS in a fixed order (bitwise
+// reproducible, no atomics).  (One thread per column walking all splits left 36 blocks on the chip for a 64 x 64 filter: 100 us.)
 __global__ __launch_bounds__(256) void slab_reduce_bf16path(const float* __restrict__ slabs, float* __restrict__ out, long n, int nsplit) {
-    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (i >= n) return;
+    __shared__ f32x4 red[256];
+    const int col = threadIdx.x & 31, kl = threadIdx.x >> 5;
+    const long i = ((long)blockIdx.x * 32 + col) * 4;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < nsplit; ++k) s += *reinterpret_cast<const f32x4*>(slabs + (long)k * n + i);
-    *reinterpret_cast<f32x4*>(out + i) = s;
+    if (i < n)
+        for (int k = kl; k < nsplit; k += 8) s += *reinterpret_cast<const f32x4*>(slabs + (long)k * n + i);
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (kl == 0 && i < n) {
+#pragma unroll
+        for (int j = 1; j < 8; ++j) s += red[j * 32 + col];
+        *reinterpret_cast<f32x4*>(out + i) = s;
+    }
 }
 
 struct WPlan { int tiles_h, tiles_w; long total; int splits, tps; };
@@ -735,6 +744,6 @@ extern "C" int runet_conv_wgrad_bf16(const float* x, int ldx, const float* dy, i
     const int tiles_c = cdiv(cin, 64) * cdiv(cout, 64);
     if (halo9) hipLaunchKernelGGL((wgrad_bf16_kernel<9>), dim3(tiles_c, 1, p.splits), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((wgrad_bf16_kernel<1>), dim3(tiles_c, ntaps, p.splits), dim3(256), 0, st, a);
-    if (p.splits > 1) hipLaunchKernelGGL(slab_reduce_bf16path, dim3(cdiv(wsize, 1024)), dim3(256), 0, st, workspace, dw, wsize, p.splits);
+    if (p.splits > 1) hipLaunchKernelGGL(slab_reduce_bf16path, dim3(cdiv(wsize, 128)), dim3(256), 0, st, workspace, dw, wsize, p.splits);
     RUNET_CHECK_LAUNCH();
 }

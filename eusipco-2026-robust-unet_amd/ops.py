@@ -128,8 +128,13 @@ def _igemm_bf16(mode, x, w_hwio, bias, out, n, h, wd, cin, cout, kh, kw, dil, ac
                                     n, h, wd, cin, cout, kh, kw, dil, mode, int(accumulate), stream()))
     if prof:
         e1.record()
-        fl = 2.0 * n * h * wd * (4 if kh == 2 else kh * kw) * cin * cout
-        _PROFILE.append(("igemm_bf16_kernel", fl, fl, e0, e1))
+        taps = 4 if kh == 2 else kh * kw
+        fl = 2.0 * n * h * wd * taps * cin * cout
+        opix = 4 * n * h * wd if mode == CONVT_FWD else n * h * wd          # pixels written (mode CONVT_DGRAD reads 4x the pixels instead)
+        ipix = 4 * n * h * wd if mode == CONVT_DGRAD else n * h * wd
+        nbytes = 4.0 * (ipix * cin + opix * cout) + 2.0 * taps * cin * cout
+        name = "conv3x3_bf16_kernel" if (kh == 3 and dil == 1 and mode in (CONV_FWD, CONV_DGRAD)) else "igemm_bf16_kernel"
+        _PROFILE.append((name, fl, fl, e0, e1, nbytes))
     return out
 
 
@@ -183,17 +188,20 @@ def stop_conv_profile(prof):
     _PROFILE = None
     torch.cuda.synchronize()
     agg = {}
-    for name, flops, xflops, e0, e1 in prof:
-        a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
+    for ent in prof:
+        name, flops, xflops, e0, e1 = ent[:5]
+        a = agg.setdefault(name, [0, 0.0, 0.0, 0.0, 0.0])
         a[0] += 1
         a[1] += e0.elapsed_time(e1) * 1e-3
         a[2] += flops
         a[3] += xflops
+        a[4] += ent[5] if len(ent) > 5 else 0.0          # algorithmic HBM bytes (bf16 kernels: activations read + written once, weights once)
     dom = max(agg, key=lambda k: agg[k][1])
-    n, t, f, xf = agg[dom]
-    by = {k: [v[0], round(v[1] * 1e3, 3), round(v[2] / v[1] / 1e12, 2), round(v[3] / v[1] / 1e12, 2)]
+    n, t, f, xf, nb = agg[dom]
+    by = {k: [v[0], round(v[1] * 1e3, 3), round(v[2] / v[1] / 1e12, 2), round(v[3] / v[1] / 1e12, 2)] + ([round(v[4] / v[1] / 1e9, 1)] if v[4] else [])
           for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
-    return {"kernel": dom, "avg_us": t / n * 1e6, "launches": n, "time_s": t, "exec_flops_total": sum(v[3] for v in agg.values()), "by_kernel": by}
+    return {"kernel": dom, "avg_us": t / n * 1e6, "launches": n, "time_s": t, "exec_flops_total": sum(v[3] for v in agg.values()), "by_kernel": by,
+            "bytes_per_s": nb / t if nb else None, "bytes_per_launch": nb / n if nb else None}
 
 
 def _igemm(mode, x, ldx, w, bias, y, ldy, n, h, wd, cin, cin_w, cout, kh, kw, dil, accumulate):
@@ -302,6 +310,7 @@ def conv_dgrad(dy, w_hwio, out=None, dil=1, accumulate=False):
 # ---- weight gradients on a side stream: nothing in the backward chain waits for them (only the optimizer / the gradient all-reduce do),
 # and they are matrix-core work while much of the chain (BatchNorm / attention backward, Winograd transforms) is HBM-bound.
 USE_WGRAD_STREAM = os.environ.get("RUNET_NO_WGRAD_STREAM", "0") != "1"
+GRAPH_SIDE = os.environ.get("RUNET_GRAPH_SIDE", "0") == "1"      # measurement knob: keep the fork / join inside a hipGraph capture
 _side = {}
 
 
@@ -311,7 +320,7 @@ class wgrad_side_stream:
 
     def __enter__(self):
         # not under hipGraph capture: a captured fork/join replays correctly but slowly (23 ms instead of 12 ms at 2x256x256 with 8 hardware queues)
-        if USE_WGRAD_STREAM and torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+        if USE_WGRAD_STREAM and torch.cuda.is_available() and (GRAPH_SIDE or not torch.cuda.is_current_stream_capturing()):
             dev = torch.cuda.current_device()
             if ("s", dev) not in _side:
                 _side[("s", dev)] = torch.cuda.Stream(device=dev)
@@ -394,7 +403,8 @@ def _wgrad_bf16(x, dy, out, n, h, w, cin, cout, kh, kw, dil, transposed):
     if prof:
         e1.record()
         fl = 2.0 * n * h * w * kh * kw * cin * cout
-        _PROFILE.append(("wgrad_bf16_kernel(+reduce)", fl, fl, e0, e1))
+        nbytes = 4.0 * n * h * w * (cin + (4 if transposed else 1) * cout) + 4.0 * kh * kw * cin * cout
+        _PROFILE.append(("wgrad_bf16_kernel", fl, fl, e0, e1, nbytes))      # the span includes the slab reduce
     return out
 
 

@@ -46,28 +46,37 @@ def test_graph_step_equals_eager_step(pkg, oracle):
     assert torch.isfinite(sb(x.to(DEV), y.to(DEV)))
 
 
-def test_graph_step_timing_report(pkg, oracle):
-    trainer = importlib.import_module("eusipco-2026-robust-unet_amd.trainer")
-    out = {}
-    for graph in (False, True):
-        torch.manual_seed(0)
-        m = pkg.RobustUNet(3, 1, 64).to(DEV).train()
-        step = trainer.TrainStep(m, graph=graph)
-        x, y = pkg.synthetic_batch(2, 256, seed=1)
-        x, y = x.to(DEV), y.to(DEV)
-        for _ in range(5):
-            step(x, y)
-        torch.cuda.synchronize()
+def _time_steps(pkg, trainer, graph, n, size, base=64, steps=20):
+    torch.manual_seed(0)
+    m = pkg.RobustUNet(3, 1, base).to(DEV).train()
+    step = trainer.TrainStep(m, graph=graph)
+    x, y = pkg.synthetic_batch(n, size, seed=1)
+    x, y = x.to(DEV), y.to(DEV)
+    for _ in range(6):
+        step(x, y)
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(3):                      # best of three windows: the box is shared
         t0 = time.perf_counter()
-        for _ in range(20):
+        for _ in range(steps):
             loss = step(x, y)
         torch.cuda.synchronize()
-        out[graph] = (time.perf_counter() - t0) / 20
-        assert torch.isfinite(loss)
-    print(f"\n2 x 256x256 train step: eager {out[False] * 1e3:.2f} ms, hipGraph {out[True] * 1e3:.2f} ms")
-    # reported, not asserted (timing on a shared box): eager 11.6-11.9 ms (weight gradients on their side stream), replay 12.3-12.8 ms
-    # (single captured stream) - the step is bound by its ~650 short kernels, not by their launches
-    assert out[True] > 0 and out[False] > 0
+        best = min(best, (time.perf_counter() - t0) / steps)
+    assert torch.isfinite(loss)
+    return best
+
+
+def test_graph_step_pays_where_the_step_is_launch_bound(pkg, oracle):
+    """BASELINE config 1 (2 x 64^2, ~650 launches of a few microseconds each): the eager step is bound by the host issuing launches
+    (measured 10.1 ms), the replayed graph by the device-side kernel boundaries (8.4 ms).  At 2 x 256^2 the GPU is the bottleneck either
+    way and the replay only loses the weight-gradient side stream (a captured fork / join replays 2x slower on this runtime: 25.4 vs
+    12.4 ms, profiles/README.md), so it may be a few per cent slower - bounded here."""
+    trainer = importlib.import_module("eusipco-2026-robust-unet_amd.trainer")
+    e1, g1 = _time_steps(pkg, trainer, False, 2, 64), _time_steps(pkg, trainer, True, 2, 64)
+    e2, g2 = _time_steps(pkg, trainer, False, 2, 256), _time_steps(pkg, trainer, True, 2, 256)
+    print(f"\n2 x 64^2: eager {e1 * 1e3:.2f} ms, hipGraph {g1 * 1e3:.2f} ms;  2 x 256^2: eager {e2 * 1e3:.2f} ms, hipGraph {g2 * 1e3:.2f} ms")
+    assert g1 <= 1.0 * e1, (g1, e1)
+    assert g2 <= 1.15 * e2, (g2, e2)
 
 
 def test_graph_replay_at_config5_tile(pkg, oracle):
