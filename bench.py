@@ -14,7 +14,7 @@ For N > 1 the line also carries `strong` (the BASELINE metric's global batch of 
 `sync_bn` (the weak run with cross-rank BatchNorm statistics): SURVEY.md section 8(d).
 
 `--config K` selects one of BASELINE.json's five configurations (1: 2x64x64; 2: 16x256x256 - the default; 3: 4x512x512 per GPU in
-bf16; 4: DeepLabV3+ 16x256x256; 5: 1x1024x1024 per GPU, bf16 operands, hipGraph-captured step when single-process).
+bf16; 4: DeepLabV3+ 16x256x256; 5: 1x1024x1024 per GPU, fp16 operands + loss scaling, hipGraph-captured step when single-process).
 
 Extra objects on the line:
   roofline     - the dominant matrix-core kernel of the step (largest accumulated launch time).  `frac` = EXECUTED multiply-add FLOPs
@@ -44,16 +44,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PKG = "eusipco-2026-robust-unet_amd"
-PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}   # MI355X_MICROARCH.md: dense matrix peaks (v_mfma_f32_32x32x2_f32 / v_mfma_f32_32x32x16_bf16)
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "fp16": 2500.0}   # MI355X_MICROARCH.md: dense matrix peaks (v_mfma_f32_32x32x2_f32 / v_mfma_f32_32x32x16_bf16)
 HBM_PEAK_GBS = 8000.0                          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured with a float4 copy)
-TRAFFIC_FILE = {"f32": "profiles/round2_pmc_traffic.json", "bf16": "profiles/round2_bf16_pmc_traffic.json"}
+TRAFFIC_FILE = {"f32": "profiles/round2_pmc_traffic.json", "bf16": "profiles/round2_bf16_pmc_traffic.json", "fp16": "profiles/round2_fp16_pmc_traffic.json"}
 
 CONFIGS = {   # BASELINE.json `configs`, per-GPU shard
     1: dict(model="runet", batch=2, size=64, dtype="f32"),
     2: dict(model="runet", batch=16, size=256, dtype="f32"),
     3: dict(model="runet", batch=4, size=512, dtype="bf16"),
     4: dict(model="deeplab", batch=16, size=256, dtype="f32"),
-    5: dict(model="runet", batch=1, size=1024, dtype="bf16", graph=True),
+    5: dict(model="runet", batch=1, size=1024, dtype="fp16", graph=True),
 }
 
 
@@ -83,10 +83,11 @@ def parse_args(argv=None):
     ap.add_argument("--global-batch", type=int, default=0, help="strong scaling: this many images split across the ranks (overrides --batch)")
     ap.add_argument("--size", type=int, default=None)
     ap.add_argument("--base", type=int, default=64)
-    ap.add_argument("--dtype", choices=["f32", "bf16"], default=None, help="operand type of the matrix-core kernels (accumulation, master weights, "
+    ap.add_argument("--dtype", choices=["f32", "bf16", "fp16"], default=None, help="operand type of the matrix-core kernels (accumulation, master weights, "
                     "BatchNorm statistics and the optimizer stay fp32)")
     ap.add_argument("--model", choices=["runet", "deeplab"], default=None)
     ap.add_argument("--graph", action="store_true", help="hipGraph-captured step (single process only)")
+    ap.add_argument("--loss-scale", type=float, default=1024.0, help="static loss scale of the fp16 mode (ignored otherwise)")
     ap.add_argument("--sync-bn", action="store_true", help="primary run with cross-rank BatchNorm statistics (results equal the global-batch step)")
     ap.add_argument("--no-extra-runs", action="store_true", help="N > 1: skip the `strong` and `sync_bn` sub-runs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -239,7 +240,7 @@ def run_rank(args):
         sync = pkg.GradAllReducer(model, sync_bn=False)
         sync.broadcast_parameters(0)
     graph = bool(args.graph) and not use_dist
-    step = pkg.TrainStep(model, lr=1e-4, weight_decay=1e-4, grad_sync=sync, graph=graph)
+    step = pkg.TrainStep(model, lr=1e-4, weight_decay=1e-4, grad_sync=sync, graph=graph, loss_scale=args.loss_scale if args.dtype == "fp16" else None)
 
     def barrier():
         torch.cuda.synchronize()
@@ -313,7 +314,8 @@ def run_rank(args):
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{name} " + (f"base{args.base} (40.9M params) " if args.model == "runet" else "") +
                                    f"train step, {args.size}x{args.size} RGB+mask tiles, batch {args.batch}/GPU, "
-                                   + ("fp32" if args.dtype == "f32" else "bf16 matrix-core operands, fp32 accumulation / master weights / BatchNorm / Adam") +
+                                   + ("fp32" if args.dtype == "f32" else f"{args.dtype} matrix-core operands, fp32 accumulation / master weights / BatchNorm / Adam"
+                                      + (f", loss scale {args.loss_scale:g}" if args.dtype == "fp16" else "")) +
                                    ", BCE + Adam(lr 1e-4, wd 1e-4), dropout + batch-stat BN on" + (", hipGraph-captured step" if graph else ""),
                        "baseline_config": args.config or 2, "global_batch": world * args.batch, "image_size": args.size,
                        "parallelism": f"dp{world}" + (f" ({comm} gradient all-reduce overlapped with backward, "
@@ -352,7 +354,7 @@ def run_rank(args):
             if alone is not None:      # [launches, total ms, algorithmic, executed] of the same kernel in three single-stream steps after the timed region
                 out["roofline"]["standalone"] = {"achieved": alone[3], "frac": round(alone[3] / peak, 4), "algorithmic": alone[2],
                                                  "avg_launch_us": round(1e3 * alone[1] / alone[0], 2)}
-            if args.dtype == "bf16" and roof.get("bytes_per_s"):
+            if args.dtype != "f32" and roof.get("bytes_per_s"):
                 # the bf16-operand kernels are HBM-bound by design (16x the fp32 matrix rate): their roofline is the memory one.
                 # achieved = ALGORITHMIC bytes (fp32 activations read once + written once + the bf16 weights) / HIP-event launch time
                 r = out["roofline"]

@@ -121,7 +121,8 @@ __global__ __launch_bounds__(TPB) void bce_bwd_kernel(const float* __restrict__ 
 constexpr int ADAM_CHUNK = 16384;
 __global__ __launch_bounds__(TPB) void adam_multi_kernel(const long long* __restrict__ table, int T, const int* __restrict__ chunks,
                                                          float lr, float beta1, float beta2, float eps, float wd, float bc1,
-                                                         float bc2_sqrt, float grad_scale) {
+                                                         float bc2_sqrt, float grad_scale, const int* __restrict__ skip) {
+    if (skip && *skip) return;      // loss-scaled step whose gradients overflowed: parameters and moments stay as they are
     const int t = chunks[blockIdx.x * 2], ck = chunks[blockIdx.x * 2 + 1];
     float* p = reinterpret_cast<float*>(table[t]);
     const float* g = reinterpret_cast<const float*>(table[T + t]);
@@ -224,9 +225,11 @@ extern "C" int runet_adam_chunk_elems(void) { return ADAM_CHUNK; }
 // ---- graph-capturable form: hyper-parameters and the step counter live in device memory, so a captured launch stays valid when
 // the learning rate changes or the step advances.  hyper = {lr, beta1, beta2, eps, weight_decay, grad_scale}.
 namespace {
-__global__ void adam_tick_kernel(int* step) { *step += 1; }
+__global__ void adam_tick_kernel(int* step, const int* skip) { if (!(skip && *skip)) *step += 1; }
 __global__ __launch_bounds__(TPB) void adam_multi_dev_kernel(const long long* __restrict__ table, int T, const int* __restrict__ chunks,
-                                                             const float* __restrict__ hyper, const int* __restrict__ step_dev) {
+                                                             const float* __restrict__ hyper, const int* __restrict__ step_dev,
+                                                             const int* __restrict__ skip) {
+    if (skip && *skip) return;
     const int t = chunks[blockIdx.x * 2], ck = chunks[blockIdx.x * 2 + 1];
     float* p = reinterpret_cast<float*>(table[t]);
     const float* g = reinterpret_cast<const float*>(table[T + t]);
@@ -252,19 +255,45 @@ __global__ __launch_bounds__(TPB) void adam_multi_dev_kernel(const long long* __
 }  // namespace
 
 extern "C" int runet_adam_multi_dev(const long long* table, int n_tensors, const int* chunks, int n_chunks, const float* hyper, int* step_dev,
-                                    void* stream) {
+                                    const int* skip_flag, void* stream) {
     RUNET_REQUIRE(table && chunks && hyper && step_dev && n_tensors > 0 && n_chunks > 0, "bad arguments");
-    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev);
-    hipLaunchKernelGGL(adam_multi_dev_kernel, dim3(n_chunks), dim3(TPB), 0, (hipStream_t)stream, table, n_tensors, chunks, hyper, step_dev);
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev, skip_flag);
+    hipLaunchKernelGGL(adam_multi_dev_kernel, dim3(n_chunks), dim3(TPB), 0, (hipStream_t)stream, table, n_tensors, chunks, hyper, step_dev, skip_flag);
+    RUNET_CHECK_LAUNCH();
+}
+
+// ---- loss scaling (fp16 operands): flag[0] = 1 if any element of buf is Inf / NaN (flag must be zeroed by the caller), flag[1] += flag[0]
+namespace {
+__global__ __launch_bounds__(TPB) void nonfinite_kernel(const float* __restrict__ buf, long n, int* __restrict__ flag) {
+    bool bad = false;
+    const long nv = n / 4;
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < nv; i += (long)gridDim.x * TPB) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(buf + i * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bad |= !(fabsf(v[e]) <= 3.4e38f);
+    }
+    if (blockIdx.x == 0)
+        for (long i = nv * 4 + threadIdx.x; i < n; i += TPB) bad |= !(fabsf(buf[i]) <= 3.4e38f);
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+__global__ void nonfinite_count_kernel(int* flag) { flag[1] += flag[0]; }
+}  // namespace
+
+extern "C" int runet_nonfinite_flag(const float* buf, long n, int* flag2, void* stream) {
+    RUNET_REQUIRE(buf && flag2 && n > 0 && ((uintptr_t)buf % 16) == 0, "bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(flag2, 0, sizeof(int), st) != hipSuccess) { runet_set_error("runet_nonfinite_flag: memset failed"); return RUNET_ELAUNCH; }
+    hipLaunchKernelGGL(nonfinite_kernel, dim3(ew_grid(n / 4 + 1)), dim3(TPB), 0, st, buf, n, flag2);
+    hipLaunchKernelGGL(nonfinite_count_kernel, dim3(1), dim3(1), 0, st, flag2);
     RUNET_CHECK_LAUNCH();
 }
 
 extern "C" int runet_adam_multi(const long long* table, int n_tensors, const int* chunks, int n_chunks, float lr, float beta1, float beta2,
-                                float eps, float weight_decay, int step, float grad_scale, void* stream) {
+                                float eps, float weight_decay, int step, float grad_scale, const int* skip_flag, void* stream) {
     RUNET_REQUIRE(table && chunks && n_tensors > 0 && n_chunks > 0 && step >= 1, "bad arguments");
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     hipLaunchKernelGGL(adam_multi_kernel, dim3(n_chunks), dim3(TPB), 0, (hipStream_t)stream, table, n_tensors, chunks, lr, beta1, beta2, eps,
-                       weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale);
+                       weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale, skip_flag);
     RUNET_CHECK_LAUNCH();
 }
 

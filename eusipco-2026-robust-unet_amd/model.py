@@ -433,8 +433,8 @@ class RobustUNet(nn.Module):
     def set_precision(self, mode):
         """'f32' (the reference's arithmetic) or 'bf16': convolution operands rounded to bf16, fp32 accumulation; parameters (fp32
         masters), activations in HBM, BatchNorm, attention, loss and optimizer stay fp32 (ops.precision)."""
-        if mode not in ("f32", "bf16"):
-            raise ValueError("precision must be 'f32' or 'bf16'")
+        if mode not in ops.PRECISIONS:
+            raise ValueError(f"precision must be one of {ops.PRECISIONS}")
         self.precision = mode
         return self
 

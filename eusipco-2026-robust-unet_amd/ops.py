@@ -41,14 +41,16 @@ def stream():
 # "bf16" (BASELINE.json configs 3 / 5): every convolution with >= 8 input channels rounds its two operands to bf16 on the way into LDS and
 # accumulates in fp32 (csrc/conv_bf16.hip); weights stay fp32 masters, activations / BatchNorm / attention / loss / Adam stay fp32.
 _PRECISION = "f32"
+PRECISIONS = ("f32", "bf16", "fp16")      # "fp16": the same kernels with IEEE half operands (needs a loss scale: trainer.TrainStep(loss_scale=...))
+_LOWP = {"bf16": (torch.bfloat16, "bf16"), "fp16": (torch.float16, "fp16")}
 
 
 class precision:
     """with ops.precision("bf16"): ...   (model.RobustUNet.set_precision wraps forward and backward in it)"""
 
     def __init__(self, mode):
-        if mode not in ("f32", "bf16"):
-            raise ValueError("precision must be 'f32' or 'bf16'")
+        if mode not in PRECISIONS:
+            raise ValueError(f"precision must be one of {PRECISIONS}")
         self.mode = mode
 
     def __enter__(self):
@@ -103,7 +105,13 @@ def transposed_weights(w_hwio):
 
 
 def _bf16_case(cin, cin_w):
-    return _PRECISION == "bf16" and cin_w == cin and cin >= 8
+    """A reduced-precision (bf16 / fp16 operand) kernel serves this convolution."""
+    return _PRECISION != "f32" and cin_w == cin and cin >= 8
+
+
+def _lp(name):
+    """C-ABI entry point of the active reduced-precision type, e.g. _lp("runet_conv_igemm_{}") -> lib.runet_conv_igemm_bf16."""
+    return getattr(lib, name.format(_LOWP[_PRECISION][1]))
 
 
 def bf16_weights(w_hwio, transpose=False):
@@ -112,10 +120,10 @@ def bf16_weights(w_hwio, transpose=False):
 
     def make():
         k, n = (cout, cin) if transpose else (cin, cout)
-        buf = torch.empty(lib.runet_bf16_pack_elems(kh * kw, k, n), device=w_hwio.device, dtype=torch.bfloat16)
-        check(lib.runet_bf16_pack_weights(w_hwio.data_ptr(), buf.data_ptr(), kh * kw, cin, cout, int(transpose), stream()))
+        buf = torch.empty(_lp("runet_{}_pack_elems")(kh * kw, k, n), device=w_hwio.device, dtype=_LOWP[_PRECISION][0])
+        check(_lp("runet_{}_pack_weights")(w_hwio.data_ptr(), buf.data_ptr(), kh * kw, cin, cout, int(transpose), stream()))
         return buf
-    return _cached(w_hwio, "bf16t" if transpose else "bf16", make)
+    return _cached(w_hwio, _PRECISION + ("t" if transpose else ""), make)
 
 
 def _igemm_bf16(mode, x, w_hwio, bias, out, n, h, wd, cin, cout, kh, kw, dil, accumulate, transpose):
@@ -124,7 +132,7 @@ def _igemm_bf16(mode, x, w_hwio, bias, out, n, h, wd, cin, cout, kh, kw, dil, ac
     if prof:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(lib.runet_conv_igemm_bf16(x.data_ptr(), ld(x), wp.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(), ld(out),
+    check(_lp("runet_conv_igemm_{}")(x.data_ptr(), ld(x), wp.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(), ld(out),
                                     n, h, wd, cin, cout, kh, kw, dil, mode, int(accumulate), stream()))
     if prof:
         e1.record()
@@ -133,7 +141,7 @@ def _igemm_bf16(mode, x, w_hwio, bias, out, n, h, wd, cin, cout, kh, kw, dil, ac
         opix = 4 * n * h * wd if mode == CONVT_FWD else n * h * wd          # pixels written (mode CONVT_DGRAD reads 4x the pixels instead)
         ipix = 4 * n * h * wd if mode == CONVT_DGRAD else n * h * wd
         nbytes = 4.0 * (ipix * cin + opix * cout) + 2.0 * taps * cin * cout
-        name = "conv3x3_bf16_kernel" if (kh == 3 and dil == 1 and mode in (CONV_FWD, CONV_DGRAD)) else "igemm_bf16_kernel"
+        name = ("conv3x3_{}_kernel" if (kh == 3 and dil == 1 and mode in (CONV_FWD, CONV_DGRAD)) else "igemm_{}_kernel").format(_PRECISION)
         _PROFILE.append((name, fl, fl, e0, e1, nbytes))
     return out
 
@@ -396,15 +404,15 @@ def _wgrad_bf16(x, dy, out, n, h, w, cin, cout, kh, kw, dil, transposed):
     if prof:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    nws = lib.runet_conv_wgrad_bf16_workspace_floats(n, h, w, cin, cout, kh, kw, dil, transposed)
+    nws = _lp("runet_conv_wgrad_{}_workspace_floats")(n, h, w, cin, cout, kh, kw, dil, transposed)
     ws = workspace(nws, x.device)
-    check(lib.runet_conv_wgrad_bf16(x.data_ptr(), ld(x), dy.data_ptr(), ld(dy), out.data_ptr(), ws.data_ptr(), ws.numel(), n, h, w, cin, cout,
+    check(_lp("runet_conv_wgrad_{}")(x.data_ptr(), ld(x), dy.data_ptr(), ld(dy), out.data_ptr(), ws.data_ptr(), ws.numel(), n, h, w, cin, cout,
                                     kh, kw, dil, transposed, stream()))
     if prof:
         e1.record()
         fl = 2.0 * n * h * w * kh * kw * cin * cout
         nbytes = 4.0 * n * h * w * (cin + (4 if transposed else 1) * cout) + 4.0 * kh * kw * cin * cout
-        _PROFILE.append(("wgrad_bf16_kernel", fl, fl, e0, e1, nbytes))      # the span includes the slab reduce
+        _PROFILE.append((f"wgrad_{_PRECISION}_kernel", fl, fl, e0, e1, nbytes))      # the span includes the slab reduce
     return out
 
 

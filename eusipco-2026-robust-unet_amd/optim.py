@@ -28,6 +28,7 @@ class FusedAdam(torch.optim.Optimizer):
         self.grad_scale = 1.0     # multiplied into the gradient (1/world_size after a SUM all-reduce)
         self.capturable = False   # True: hyper-parameters and the step counter are read from device memory (hipGraph replay, trainer.TrainStep)
         self._dev_state = {}      # group index -> (hyper float[6], step int32[1], host copy of hyper)
+        self.skip_flag = None     # device int32[2] set by trainer.TrainStep under loss scaling: [0] != 0 -> this update is skipped on the device
 
     def _device_hyper(self, gi, group, dev, step_host):
         b1, b2 = group["betas"]
@@ -106,10 +107,12 @@ class FusedAdam(torch.optim.Optimizer):
                 else:
                     hyper, step_dev, _ = self._device_hyper(gi, group, plist[0].device, step - 1)
                 check(lib.runet_adam_multi_dev(d_tab.data_ptr(), len(plist), d_chunks.data_ptr(), n_chunks, hyper.data_ptr(), step_dev.data_ptr(),
+                                               self.skip_flag.data_ptr() if self.skip_flag is not None else None,
                                                torch.cuda.current_stream().cuda_stream))
                 continue
             b1, b2 = group["betas"]
             check(lib.runet_adam_multi(d_tab.data_ptr(), len(plist), d_chunks.data_ptr(), n_chunks, float(group["lr"]), float(b1), float(b2),
                                        float(group["eps"]), float(group["weight_decay"]), int(step), float(self.grad_scale),
+                                       self.skip_flag.data_ptr() if self.skip_flag is not None else None,
                                        torch.cuda.current_stream().cuda_stream))
         return loss

@@ -6,6 +6,7 @@ from __future__ import annotations
 import torch
 
 from . import ops
+from ._lib import check, lib
 from .optim import FusedAdam
 
 
@@ -32,12 +33,24 @@ class TrainStep:
     gradient all-reduce (RCCL capture is not wired up) and a FusedAdam in capturable mode (device-side step counter and
     hyper-parameters, so LR schedulers keep working without re-capture)."""
 
-    def __init__(self, model, lr=1e-4, weight_decay=1e-4, grad_sync=None, graph=False, graph_warmup=2):
+    def __init__(self, model, lr=1e-4, weight_decay=1e-4, grad_sync=None, graph=False, graph_warmup=2, loss_scale=None):
+        """loss_scale (fp16 operands: model.set_precision("fp16")): the loss is multiplied by it before backward so that the gradients
+        the data-gradient / weight-gradient kernels round to fp16 stay above its 6e-5 normal range; the fused Adam divides it out again
+        (grad_scale), a device-side check finds Inf / NaN gradients and makes the optimizer skip that step without a host round trip
+        (hipGraph-capturable).  `adjust_loss_scale()` (one host sync; call it once per epoch) halves the scale after skipped steps and
+        doubles it after `scale_window` clean ones, like torch.amp.GradScaler."""
         self.model = model
         self.optimizer = FusedAdam(model.parameters(), lr=lr, weight_decay=weight_decay)
         self.grad_sync = grad_sync
         if grad_sync is not None:
             grad_sync.attach(self.optimizer)
+        self.loss_scale = float(loss_scale) if loss_scale else None
+        self.scale_window, self._clean_steps, self._seen_skips = 2000, 0, 0
+        if self.loss_scale is not None:
+            self.optimizer.capturable = True          # step counter on the device: a skipped step must not advance the bias correction
+            self._base_grad_scale = self.optimizer.grad_scale
+            self.optimizer.grad_scale = self._base_grad_scale / self.loss_scale
+            self._flag = None
         self.graph_mode = bool(graph)
         if self.graph_mode:
             if grad_sync is not None:
@@ -51,11 +64,38 @@ class TrainStep:
     def _body(self, images, masks):
         self.optimizer.zero_grad(set_to_none=True)
         loss = segmentation_loss(self.model(images), masks)
-        loss.backward()
+        if self.loss_scale is None:
+            loss.backward()
+        else:
+            (loss * self.loss_scale).backward()
         if self.grad_sync is not None:
             self.grad_sync.finish()
+        if self.loss_scale is not None:
+            flat = self.model.grad_arena().flat if hasattr(self.model, "grad_arena") else None
+            if flat is None:
+                raise TypeError("loss scaling needs a model with a flat gradient arena (RobustUNet)")
+            if self._flag is None:
+                self._flag = torch.zeros(2, device=flat.device, dtype=torch.int32)
+                self.optimizer.skip_flag = self._flag
+            check(lib.runet_nonfinite_flag(flat.data_ptr(), flat.numel(), self._flag.data_ptr(), ops.stream()))
         self.optimizer.step()
         return loss
+
+    def adjust_loss_scale(self):
+        """Dynamic loss scale (one host sync): -> (current scale, steps skipped so far)."""
+        if self.loss_scale is None or self._flag is None:
+            return self.loss_scale, 0
+        skipped = int(self._flag[1].item())
+        if skipped > self._seen_skips:
+            self.loss_scale = max(1.0, self.loss_scale / 2.0 ** min(4, skipped - self._seen_skips))
+            self._clean_steps = 0
+        else:
+            self._clean_steps += 1
+            if self._clean_steps >= self.scale_window:
+                self.loss_scale, self._clean_steps = self.loss_scale * 2.0, 0
+        self._seen_skips = skipped
+        self.optimizer.grad_scale = self._base_grad_scale / self.loss_scale
+        return self.loss_scale, skipped
 
     def __call__(self, images, masks):
         if not self.graph_mode:

@@ -61,8 +61,8 @@ class UNet(nn.Module):
         self.precision = "f32"
 
     def set_precision(self, mode):
-        if mode not in ("f32", "bf16"):
-            raise ValueError("precision must be 'f32' or 'bf16'")
+        if mode not in ops.PRECISIONS:
+            raise ValueError(f"precision must be one of {ops.PRECISIONS}")
         self.precision = mode
         return self
 

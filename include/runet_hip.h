@@ -170,14 +170,18 @@ int runet_bce_bwd(const float* prob, const float* target, const float* grad_out,
 /* ---- torch.optim.Adam(lr, weight_decay) (Main_Final.py:552,582), all tensors in one launch ----
  * table: device int64 [5][n_tensors] = param, grad, exp_avg, exp_avg_sq pointers, element counts;
  * chunks: device int32 [n_chunks][2] = (tensor index, chunk index), chunk = runet_adam_chunk_elems() elements.
- * grad_scale multiplies the gradient first (1/world_size after a sum all-reduce). */
+ * grad_scale multiplies the gradient first (1/world_size after a sum all-reduce, 1/loss_scale under loss scaling).
+ * skip_flag (may be NULL): device int; non-zero -> the whole update is skipped (runet_nonfinite_flag found Inf / NaN gradients). */
 int runet_adam_chunk_elems(void);
 int runet_adam_multi(const long long* table, int n_tensors, const int* chunks, int n_chunks, float lr, float beta1, float beta2, float eps,
-                     float weight_decay, int step, float grad_scale, void* stream);
+                     float weight_decay, int step, float grad_scale, const int* skip_flag, void* stream);
 
 /* hipGraph-capturable form: hyper = device float[6] {lr, beta1, beta2, eps, weight_decay, grad_scale}; *step_dev is incremented on the
  * device and then used for the bias corrections, so one captured launch serves every step and every learning rate. */
-int runet_adam_multi_dev(const long long* table, int n_tensors, const int* chunks, int n_chunks, const float* hyper, int* step_dev, void* stream);
+int runet_adam_multi_dev(const long long* table, int n_tensors, const int* chunks, int n_chunks, const float* hyper, int* step_dev,
+                         const int* skip_flag, void* stream);
+/* loss scaling: flag2[0] = 1 iff buf[0:n] holds an Inf / NaN (reset by this call), flag2[1] += flag2[0] (running count of skipped steps) */
+int runet_nonfinite_flag(const float* buf, long n, int* flag2, void* stream);
 
 /* ---- ModelEvaluator.calculate_metrics counts (Main_Final.py:519-547): counts[n] = {tp, pred>thr, target!=0, agree} ---- */
 int runet_seg_counts(const float* pred, const float* target, long long* counts, int n_img, long per_img, float threshold, void* stream);
@@ -249,13 +253,23 @@ int runet_head3x3_bwd(const float* dprob, const float* prob, const float* x, int
  *   transpose == 0: K = cin, N = cout (forward, k2-s2 transposed forward);  transpose != 0: K = cout, N = cin (data gradients).
  *   `packed` holds runet_bf16_pack_elems(taps, K, N) 16-bit elements.
  * runet_conv_igemm_bf16: same modes / geometry as runet_conv_igemm (cin_w == cin), weights from runet_bf16_pack_weights.
- * runet_conv_wgrad_bf16: same contract as runet_conv_wgrad (cin_w == cin; dil only for 3x3). */
+ * runet_conv_wgrad_bf16: same contract as runet_conv_wgrad (cin_w == cin; dil only for 3x3).
+ * The *_fp16 entry points are the same kernels with IEEE half operands (BASELINE config 5 names fp16; csrc/conv_fp16.hip); train with a
+ * loss scale (runet_nonfinite_flag + the skip_flag of the fused Adam). */
 long runet_bf16_pack_elems(int taps, int k, int n);
 int runet_bf16_pack_weights(const float* w_hwio, void* packed, int taps, int cin, int cout, int transpose, void* stream);
 int runet_conv_igemm_bf16(const float* x, int ldx, const void* wpacked, const float* bias, float* y, int ldy, int n_img, int h, int w_,
                           int cin, int cout, int kh, int kw, int dil, int mode, int accumulate, void* stream);
 long runet_conv_wgrad_bf16_workspace_floats(int n_img, int h, int w_, int cin, int cout, int kh, int kw, int dil, int transposed);
 int runet_conv_wgrad_bf16(const float* x, int ldx, const float* dy, int ldy, float* dw, float* workspace, long workspace_floats,
+                          int n_img, int h, int w_, int cin, int cout, int kh, int kw, int dil, int transposed, void* stream);
+
+long runet_fp16_pack_elems(int taps, int k, int n);
+int runet_fp16_pack_weights(const float* w_hwio, void* packed, int taps, int cin, int cout, int transpose, void* stream);
+int runet_conv_igemm_fp16(const float* x, int ldx, const void* wpacked, const float* bias, float* y, int ldy, int n_img, int h, int w_,
+                          int cin, int cout, int kh, int kw, int dil, int mode, int accumulate, void* stream);
+long runet_conv_wgrad_fp16_workspace_floats(int n_img, int h, int w_, int cin, int cout, int kh, int kw, int dil, int transposed);
+int runet_conv_wgrad_fp16(const float* x, int ldx, const float* dy, int ldy, float* dw, float* workspace, long workspace_floats,
                           int n_img, int h, int w_, int cin, int cout, int kh, int kw, int dil, int transposed, void* stream);
 
 /* ---- harness helpers (Main_Final.py:577-578,596-597,648-649: `F.interpolate(outputs, size=masks.shape[-2:], mode='bilinear',

@@ -29,7 +29,7 @@ def test_config_presets_follow_baseline_json():
     a = bench.parse_args(["--config", "3"])
     assert (a.batch, a.size, a.dtype) == (4, 512, "bf16")
     a = bench.parse_args(["--config", "5"])
-    assert (a.batch, a.size, a.dtype, a.graph) == (1, 1024, "bf16", True)
+    assert (a.batch, a.size, a.dtype, a.graph) == (1, 1024, "fp16", True)
     a = bench.parse_args(["--config", "4"])
     assert a.model == "deeplab"
     a = bench.parse_args(["--config", "1", "--batch", "8"])

@@ -28,8 +28,8 @@ def _ops():
     return importlib.import_module("eusipco-2026-robust-unet_amd.ops")
 
 
-def _r(t):
-    return t.bfloat16().float()
+def _r(t, prec="bf16"):
+    return (t.bfloat16() if prec == "bf16" else t.half()).float()
 
 
 def _close(a, b, name, tol=2e-4):
@@ -43,6 +43,16 @@ def _close(a, b, name, tol=2e-4):
                                                   (1, 8, 8, 256, 128, 1, 1), (2, 16, 16, 32, 32, 3, 2), (1, 16, 16, 64, 64, 3, 4), (3, 4, 4, 8, 12, 3, 1),
                                                   (2, 64, 64, 64, 128, 3, 1)])
 def test_bf16_conv_fwd_dgrad_wgrad_equal_fp32_conv_of_rounded_operands(n, h, w, cin, cout, k, dil):
+    _conv_case(n, h, w, cin, cout, k, dil, "bf16")
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout,k,dil", [(2, 32, 32, 64, 64, 3, 1), (1, 20, 24, 16, 48, 3, 1), (2, 16, 16, 64, 32, 1, 1), (2, 16, 16, 32, 32, 3, 2)])
+def test_fp16_conv_fwd_dgrad_wgrad_equal_fp32_conv_of_rounded_operands(n, h, w, cin, cout, k, dil):
+    """The same kernels with IEEE half operands (BASELINE config 5 names fp16)."""
+    _conv_case(n, h, w, cin, cout, k, dil, "fp16")
+
+
+def _conv_case(n, h, w, cin, cout, k, dil, prec):
     ops = _ops()
     g = torch.Generator().manual_seed(n * 1000 + h + cin + cout + k + dil)
     x = torch.randn(n, cin, h, w, generator=g)
@@ -50,13 +60,13 @@ def test_bf16_conv_fwd_dgrad_wgrad_equal_fp32_conv_of_rounded_operands(n, h, w, 
     b = torch.randn(cout, generator=g)
     gy = torch.randn(n, cout, h, w, generator=g)
     pad = dil * (k // 2)
-    xr, wr, gr = _r(x).requires_grad_(True), _r(wt).requires_grad_(True), _r(gy)
+    xr, wr, gr = _r(x, prec).requires_grad_(True), _r(wt, prec).requires_grad_(True), _r(gy, prec)
     yr = F.conv2d(xr, wr, b, padding=pad, dilation=dil)
     yr.backward(gr)                                       # reference data / weight gradients from rounded dy as well
     xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
     wd = wt.permute(2, 3, 1, 0).contiguous().to(DEV)      # HWIO
     gd = gy.permute(0, 2, 3, 1).contiguous().to(DEV)
-    with ops.precision("bf16"):
+    with ops.precision(prec):
         y = ops.conv_fwd(xd, wd, b.to(DEV), dil=dil)
         dx = ops.conv_dgrad(gd, wd, dil=dil)
         dw = ops.conv_wgrad(xd, gd, k, k, dil=dil, on_side=False)
@@ -162,3 +172,46 @@ def test_bf16_config3_and_config5_train_steps(pkg, oracle):
         assert res[0][0] == res[1][0]
         for a, b in zip(res[0][1], res[1][1]):
             assert torch.equal(a, b)
+
+
+def test_fp16_train_step_with_loss_scaling(pkg, oracle):
+    """fp16 operands (config 5): one step at loss scale 1024 against the fp32 oracle (fp16 keeps 11 significant bits: tighter than the bf16
+    bands - logits within 0.5 % of their scale, gradient cosine >= 0.995), the Adam update un-scaled (parameters move by ~lr, not ~1024 lr),
+    and a step whose scaled gradients overflow is skipped ON THE DEVICE: parameters, moments and the step counter untouched, skip counted."""
+    trainer = importlib.import_module("eusipco-2026-robust-unet_amd.trainer")
+    base, n, size, seed = 64, 2, 64, 5
+    st = oracle.init_state(3, 1, base, seed=seed, perturb_bn=True)
+    masks = oracle.dropout_masks(n, base, seed=seed)
+    x, y = pkg.synthetic_batch(n, size, seed=seed)
+    model = pkg.RobustUNet(3, 1, base)
+    model.load_state_dict(st)
+    model = model.to(DEV).train().set_precision("fp16")
+    model.set_dropout_masks(masks)
+    step = trainer.TrainStep(model, lr=1e-4, weight_decay=0.0, loss_scale=1024.0)
+    before = {k: p.detach().clone() for k, p in model.named_parameters()}
+    loss = step(x.to(DEV), y.to(DEV))
+    names = oracle.param_names(3, 1, base)
+    P = {k: v.clone() for k, v in st.items()}
+    for k in names:
+        P[k].requires_grad_(True)
+    rp, rl = oracle.forward(P, x, True, masks)
+    rloss = oracle.bce_mean(rp, y)
+    rloss.backward()
+    assert abs(float(loss) - float(rloss)) <= 2e-3 * max(1.0, abs(float(rloss)))
+    g = torch.cat([(p.grad.detach().cpu().double() / 1024.0).reshape(-1) for p in model.parameters()])      # p.grad holds the SCALED gradient
+    r = torch.cat([P[k].grad.double().reshape(-1) for k in names])
+    cos = float((g @ r) / (g.norm() * r.norm()))
+    print(f"\nfp16 step: loss {float(loss):.5f} vs {float(rloss):.5f}, gradient cosine {cos:.5f}")
+    assert cos >= 0.995
+    moved = torch.cat([(p.detach() - before[k]).abs().reshape(-1) for k, p in model.named_parameters()])
+    assert 0 < float(moved.max()) <= 1.05e-4                     # first Adam step: |dp| <= lr, whatever the loss scale
+    assert step.adjust_loss_scale() == (1024.0, 0)
+    # overflow: an absurd scale makes the scaled gradients Inf -> the device-side flag makes Adam skip
+    step.loss_scale = 1e38
+    step.optimizer.grad_scale = 1.0 / 1e38
+    snap = {k: p.detach().clone() for k, p in model.named_parameters()}
+    step(x.to(DEV), y.to(DEV))
+    for k, p in model.named_parameters():
+        assert torch.equal(p.detach(), snap[k]), k
+    scale, skipped = step.adjust_loss_scale()
+    assert skipped == 1 and scale < 1e38
