@@ -76,8 +76,8 @@ def log(msg):
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", type=int, default=0, choices=[0, 1, 2, 3, 4, 5], help="BASELINE.json configuration (default: 2)")
     ap.add_argument("--batch", type=int, default=None, help="images per GPU")
     ap.add_argument("--global-batch", type=int, default=0, help="strong scaling: this many images split across the ranks (overrides --batch)")

@@ -51,7 +51,26 @@ class ASPP(nn.Module):
         self.bn = BatchNorm2d(out_channels)
 
     def forward(self, x):
-        raise NotImplementedError("ASPP is executed inside DeepLabV3Plus.forward's kernel sequence")
+        """Standalone call (inside DeepLabV3Plus the same kernel sequence runs as part of the network's single autograd node)."""
+        _require_cuda(x)
+        return _ASPPFn.apply(x, self, *[p for _, p in self.named_parameters()])
+
+
+class _ASPPFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mod, *params):
+        xn = x.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
+        out, ctx.c = aspp_forward(mod, xn, mod.training, B.Small(x.device))
+        ctx.mod = mod
+        return out.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, dy):
+        G = {}
+        dyn = dy.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
+        dx = aspp_backward(ctx.c, dyn, G, "", dy.device, B.Small(dy.device), ops.stream())
+        ctx.c = None
+        return (dx.permute(0, 3, 1, 2), None) + tuple(G[k] for k, _ in ctx.mod.named_parameters())
 
 
 class DeepLabV3Plus(nn.Module):
@@ -94,6 +113,86 @@ def _conv_bn_relu(x, conv, bn, training, sm, fwd):
     return act, dict(x=x, w=w, raw=raw, act=act, s=s, mean=mean, invstd=invstd, training=training)
 
 
+def aspp_forward(asp: ASPP, a4, tr, sm):
+    """ASPP (Main_Final.py:325-357) on an NHWC tensor: four parallel convolutions (1x1, 3x3 dilation 6 / 12 / 18) + the image-pooling branch,
+    written into fifths of one buffer, then the 1x1 output convolution + BatchNorm + ReLU.  -> (out, ctx)"""
+    dev = a4.device
+    n = a4.shape[0]
+    _, h4, w4, c4 = a4.shape
+    q = asp.conv1.out_channels
+    cat = ops.empty_nhwc(n, h4, w4, 5 * q, a4)
+    ws = [ops.hwio(c.weight) for c in (asp.conv1, asp.conv2, asp.conv3, asp.conv4, asp.conv5, asp.conv_out)]
+    ops.conv_fwd(a4, ws[0], asp.conv1.bias, out=cat[..., 0:q])
+    for i, (cv, d) in enumerate(((asp.conv2, 6), (asp.conv3, 12), (asp.conv4, 18))):
+        ops.conv_general_fwd(a4, ws[1 + i], cv.bias, 1, d, d, out=cat[..., (1 + i) * q:(2 + i) * q])
+    pooled, m2 = sm.f(n * c4), sm.f(n * c4)
+    wsp = B._ws(n, h4 * w4, c4, dev)
+    check(lib.runet_chan_stats(a4.data_ptr(), ops.ld(a4), n, h4 * w4, c4, wsp.data_ptr(), pooled.data_ptr(), m2.data_ptr(), None, None, None, None, 0,
+                               ops.stream()))
+    pooled4 = pooled.view(n, 1, 1, c4)
+    x5 = ops.conv_fwd(pooled4, ws[4], asp.conv5.bias)                       # [n,1,1,q]
+    check(lib.runet_broadcast_nc(x5.data_ptr(), cat[..., 4 * q:].data_ptr(), ops.ld(cat), n, h4 * w4, q, ops.stream()))
+    co = ops.conv_fwd(cat, ws[5], asp.conv_out.bias)
+    s, hsh, mean, invstd, _ = B.bn_coeff(co, asp.bn.state(), tr, sm)
+    aa = B.bn_apply(co, s, hsh, None, relu=True)
+    return aa, dict(a4=a4, cat=cat, pooled4=pooled4, ws=ws, co=co, aa=aa, s=s, mean=mean, invstd=invstd, q=q, training=tr)
+
+
+def aspp_backward(a, dy, G, pre, dev, sm, st):
+    """Backward of aspp_forward: parameter gradients into G under `pre` (logical shapes), -> gradient of the input."""
+
+    def conv_w(name, t):
+        G[name] = t.permute(3, 2, 0, 1)
+
+    def bias_grad(name, t):
+        out = torch.empty(t.shape[3], device=dev, dtype=torch.float32)
+        B.chan_sum(t, out)
+        G[name] = out
+
+    q = a["q"]
+    nco = a["co"].shape[3]
+    sums = torch.empty(2 * nco, device=dev, dtype=torch.float32)
+    dco = B.bn_backward(dy, a["co"], a["mean"], a["invstd"], a["s"], sums, act=a["aa"], training=a["training"])
+    G[pre + "bn.weight"], G[pre + "bn.bias"] = sums[:nco], sums[nco:]
+    ws = a["ws"]
+    cat, a4 = a["cat"], a["a4"]
+    conv_w(pre + "conv_out.weight", ops.conv_wgrad(cat, dco, 1, 1))
+    bias_grad(pre + "conv_out.bias", dco)
+    dcat = ops.conv_dgrad(dco, ws[5])
+    n4, h4, w4, c4 = a4.shape
+    da4 = ops.conv_dgrad(dcat[..., 0:q], ws[0])
+    conv_w(pre + "conv1.weight", ops.conv_wgrad(a4, dcat[..., 0:q], 1, 1))
+    bias_grad(pre + "conv1.bias", dcat[..., 0:q])
+    for i, d in enumerate((6, 12, 18)):
+        sl = dcat[..., (1 + i) * q:(2 + i) * q]
+        conv_w(pre + f"conv{2 + i}.weight", ops.conv_general_wgrad(a4, sl, 3, 3, 1, d, d))
+        bias_grad(pre + f"conv{2 + i}.bias", sl)
+        ops.conv_general_dgrad(sl, ws[1 + i], h4, w4, 1, d, d, out=da4, accumulate=True)
+    # image-pooling branch: d(x5)[n,c] = sum over pixels of the broadcast slice; then 1x1 conv backward; then the mean's backward
+    dx5 = torch.empty((n4, 1, 1, q), device=dev, dtype=torch.float32)
+    sl5 = dcat[..., 4 * q:]
+    mean_nc, m2_nc = sm.f(n4 * q), sm.f(n4 * q)
+    wsp = B._ws(n4, h4 * w4, q, dev)
+    check(lib.runet_chan_stats(sl5.data_ptr(), ops.ld(sl5), n4, h4 * w4, q, wsp.data_ptr(), mean_nc.data_ptr(), m2_nc.data_ptr(), None, None, None,
+                               None, 0, st))
+    # dx5 = mean * HW (sum over pixels): fold the HW factor into bn_apply-style scale
+    ones = torch.full((q,), float(h4 * w4), device=dev, dtype=torch.float32)
+    zeros = torch.zeros(q, device=dev, dtype=torch.float32)
+    B.bn_apply(mean_nc.view(n4, 1, 1, q), ones, zeros, None, relu=False, out=dx5)
+    conv_w(pre + "conv5.weight", ops.conv_wgrad(a["pooled4"], dx5, 1, 1))
+    bias_grad(pre + "conv5.bias", dx5)
+    dpooled = ops.conv_dgrad(dx5, ws[4])                                   # [n,1,1,512]; each pixel gets dpooled / HW
+    inv = torch.full((c4,), 1.0 / float(h4 * w4), device=dev, dtype=torch.float32)
+    dpool_s = ops.empty_nhwc(n4, 1, 1, c4, a4)
+    B.bn_apply(dpooled, inv, torch.zeros(c4, device=dev, dtype=torch.float32), None, relu=False, out=dpool_s)
+    bc = ops.empty_nhwc(n4, h4, w4, c4, a4)
+    check(lib.runet_broadcast_nc(dpool_s.data_ptr(), bc.data_ptr(), ops.ld(bc), n4, h4 * w4, c4, st))
+    # da4 += broadcast: reuse the accumulate path of a 1x1 identity?  simpler: bn_apply has no accumulate, so add through torch-free axpy:
+    # use conv_dgrad's accumulate with an identity is wasteful; instead finish with one elementwise kernel below
+    _add_inplace(da4, bc)
+    return da4
+
+
 def dl_forward(net: DeepLabV3Plus, x, save=True):
     tr = net.training
     dev = x.device
@@ -112,25 +211,7 @@ def dl_forward(net: DeepLabV3Plus, x, save=True):
     a3, C["conv3"] = _conv_bn_relu(a2, net.conv3[0], net.conv3[1], tr, sm, lambda t, w, b: ops.conv_general_fwd(t, w, b, 2, 1))
     a4, C["conv4"] = _conv_bn_relu(a3, net.conv4[0], net.conv4[1], tr, sm, lambda t, w, b: ops.conv_general_fwd(t, w, b, 2, 1))
     # ---- ASPP
-    asp = net.aspp
-    _, h4, w4, c4 = a4.shape
-    q = asp.conv1.out_channels
-    cat = ops.empty_nhwc(n, h4, w4, 5 * q, a4)
-    ws = [ops.hwio(c.weight) for c in (asp.conv1, asp.conv2, asp.conv3, asp.conv4, asp.conv5, asp.conv_out)]
-    ops.conv_fwd(a4, ws[0], asp.conv1.bias, out=cat[..., 0:q])
-    for i, (cv, d) in enumerate(((asp.conv2, 6), (asp.conv3, 12), (asp.conv4, 18))):
-        ops.conv_general_fwd(a4, ws[1 + i], cv.bias, 1, d, d, out=cat[..., (1 + i) * q:(2 + i) * q])
-    pooled, m2 = sm.f(n * c4), sm.f(n * c4)
-    wsp = B._ws(n, h4 * w4, c4, dev)
-    check(lib.runet_chan_stats(a4.data_ptr(), ops.ld(a4), n, h4 * w4, c4, wsp.data_ptr(), pooled.data_ptr(), m2.data_ptr(), None, None, None, None, 0,
-                               ops.stream()))
-    pooled4 = pooled.view(n, 1, 1, c4)
-    x5 = ops.conv_fwd(pooled4, ws[4], asp.conv5.bias)                       # [n,1,1,q]
-    check(lib.runet_broadcast_nc(x5.data_ptr(), cat[..., 4 * q:].data_ptr(), ops.ld(cat), n, h4 * w4, q, ops.stream()))
-    co = ops.conv_fwd(cat, ws[5], asp.conv_out.bias)
-    s, hsh, mean, invstd, _ = B.bn_coeff(co, asp.bn.state(), tr, sm)
-    aa = B.bn_apply(co, s, hsh, None, relu=True)
-    C["aspp"] = dict(a4=a4, cat=cat, pooled4=pooled4, ws=ws, co=co, aa=aa, s=s, mean=mean, invstd=invstd, q=q, training=tr)
+    aa, C["aspp"] = aspp_forward(net.aspp, a4, tr, sm)
     # ---- decoder
     y = aa
     for i in range(4):
@@ -188,49 +269,7 @@ def dl_backward(net: DeepLabV3Plus, C, dprob):
         bias_grad(f"decoder.{3 * i}.bias", draw)
         dy = ops.convt4_dgrad(draw, c["w"])
     # ---- ASPP
-    a = C["aspp"]
-    asp = net.aspp
-    q = a["q"]
-    nco = a["co"].shape[3]
-    sums = torch.empty(2 * nco, device=dev, dtype=torch.float32)
-    dco = B.bn_backward(dy, a["co"], a["mean"], a["invstd"], a["s"], sums, act=a["aa"], training=a["training"])
-    G["aspp.bn.weight"], G["aspp.bn.bias"] = sums[:nco], sums[nco:]
-    ws = a["ws"]
-    cat, a4 = a["cat"], a["a4"]
-    conv_w("aspp.conv_out.weight", ops.conv_wgrad(cat, dco, 1, 1))
-    bias_grad("aspp.conv_out.bias", dco)
-    dcat = ops.conv_dgrad(dco, ws[5])
-    n4, h4, w4, c4 = a4.shape
-    da4 = ops.conv_dgrad(dcat[..., 0:q], ws[0])
-    conv_w("aspp.conv1.weight", ops.conv_wgrad(a4, dcat[..., 0:q], 1, 1))
-    bias_grad("aspp.conv1.bias", dcat[..., 0:q])
-    for i, d in enumerate((6, 12, 18)):
-        sl = dcat[..., (1 + i) * q:(2 + i) * q]
-        conv_w(f"aspp.conv{2 + i}.weight", ops.conv_general_wgrad(a4, sl, 3, 3, 1, d, d))
-        bias_grad(f"aspp.conv{2 + i}.bias", sl)
-        ops.conv_general_dgrad(sl, ws[1 + i], h4, w4, 1, d, d, out=da4, accumulate=True)
-    # image-pooling branch: d(x5)[n,c] = sum over pixels of the broadcast slice; then 1x1 conv backward; then the mean's backward
-    dx5 = torch.empty((n4, 1, 1, q), device=dev, dtype=torch.float32)
-    sl5 = dcat[..., 4 * q:]
-    mean_nc, m2_nc = sm.f(n4 * q), sm.f(n4 * q)
-    wsp = B._ws(n4, h4 * w4, q, dev)
-    check(lib.runet_chan_stats(sl5.data_ptr(), ops.ld(sl5), n4, h4 * w4, q, wsp.data_ptr(), mean_nc.data_ptr(), m2_nc.data_ptr(), None, None, None,
-                               None, 0, st))
-    # dx5 = mean * HW (sum over pixels): fold the HW factor into bn_apply-style scale
-    ones = torch.full((q,), float(h4 * w4), device=dev, dtype=torch.float32)
-    zeros = torch.zeros(q, device=dev, dtype=torch.float32)
-    B.bn_apply(mean_nc.view(n4, 1, 1, q), ones, zeros, None, relu=False, out=dx5)
-    conv_w("aspp.conv5.weight", ops.conv_wgrad(a["pooled4"], dx5, 1, 1))
-    bias_grad("aspp.conv5.bias", dx5)
-    dpooled = ops.conv_dgrad(dx5, ws[4])                                   # [n,1,1,512]; each pixel gets dpooled / HW
-    inv = torch.full((c4,), 1.0 / float(h4 * w4), device=dev, dtype=torch.float32)
-    dpool_s = ops.empty_nhwc(n4, 1, 1, c4, a4)
-    B.bn_apply(dpooled, inv, torch.zeros(c4, device=dev, dtype=torch.float32), None, relu=False, out=dpool_s)
-    bc = ops.empty_nhwc(n4, h4, w4, c4, a4)
-    check(lib.runet_broadcast_nc(dpool_s.data_ptr(), bc.data_ptr(), ops.ld(bc), n4, h4 * w4, c4, st))
-    # da4 += broadcast: reuse the accumulate path of a 1x1 identity?  simpler: bn_apply has no accumulate, so add through torch-free axpy:
-    # use conv_dgrad's accumulate with an identity is wasteful; instead finish with one elementwise kernel below
-    _add_inplace(da4, bc)
+    da4 = aspp_backward(C["aspp"], dy, G, "aspp.", dev, sm, st)
     # ---- backbone
     c = C["conv4"]
     draw = bn_back("conv4.1", c, da4)

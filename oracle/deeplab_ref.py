@@ -74,6 +74,17 @@ def _conv(P, name, x, stride=1, padding=0, dilation=1):
     return F.conv2d(x, P[f"{name}.weight"], P[f"{name}.bias"], stride, padding, dilation)
 
 
+def aspp(P, x, training=True):
+    """ASPP (Main_Final.py:325-357) on its own: keys "aspp.*" of the state."""
+    size = x.shape[2:]
+    branches = [_conv(P, "aspp.conv1", x)]
+    for i, d in ((2, 6), (3, 12), (4, 18)):
+        branches.append(_conv(P, f"aspp.conv{i}", x, 1, d, d))
+    pooled = _conv(P, "aspp.conv5", F.adaptive_avg_pool2d(x, 1))
+    branches.append(F.interpolate(pooled, size=size, mode="bilinear", align_corners=False))
+    return _bn_relu(P, "aspp.bn", _conv(P, "aspp.conv_out", torch.cat(branches, 1)), training)
+
+
 def forward(P, x, training=True, taps=None):
     """P: state dict (tensors; parameters may require grad).  -> sigmoid probabilities [N,1,H,W]"""
     def tap(k, v):
@@ -85,13 +96,7 @@ def forward(P, x, training=True, taps=None):
     x = tap("conv2", _bn_relu(P, "conv2.2", _conv(P, "conv2.1", x, 1, 1), training))
     x = tap("conv3", _bn_relu(P, "conv3.1", _conv(P, "conv3.0", x, 2, 1), training))
     x = tap("conv4", _bn_relu(P, "conv4.1", _conv(P, "conv4.0", x, 2, 1), training))
-    size = x.shape[2:]
-    branches = [_conv(P, "aspp.conv1", x)]
-    for i, d in ((2, 6), (3, 12), (4, 18)):
-        branches.append(_conv(P, f"aspp.conv{i}", x, 1, d, d))
-    pooled = _conv(P, "aspp.conv5", F.adaptive_avg_pool2d(x, 1))
-    branches.append(F.interpolate(pooled, size=size, mode="bilinear", align_corners=False))
-    x = tap("aspp", _bn_relu(P, "aspp.bn", _conv(P, "aspp.conv_out", torch.cat(branches, 1)), training))
+    x = tap("aspp", aspp(P, x, training))
     for i in (0, 3, 6, 9):
         x = F.conv_transpose2d(x, P[f"decoder.{i}.weight"], P[f"decoder.{i}.bias"], stride=2, padding=1)
         x = tap(f"decoder.{i}", _bn_relu(P, f"decoder.{i + 1}", x, training))

@@ -185,3 +185,37 @@ def test_deeplab_train_step_matches_reference(pkg, tag):
     with torch.no_grad():
         pe = model(x)
     np.testing.assert_allclose(pe.cpu().numpy(), gold["eval_prob"], rtol=0, atol=2e-3)
+
+
+def test_aspp_standalone_matches_the_oracle(pkg):
+    """ASPP called on its own (Main_Final.py:325-357; the reference class is callable): forward, input gradient and every parameter gradient
+    against the DeepLabV3+ oracle's ASPP (itself pinned by the full-model goldens)."""
+    dl = importlib.import_module("oracle.deeplab_ref")
+    dev = torch.device("cuda:0")
+    st = {k[5:]: v for k, v in dl.init_state(seed=3, perturb_bn=True).items() if k.startswith("aspp.")}
+    mod = pkg.ASPP(512, 256)
+    res = mod.load_state_dict(st, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    mod = mod.to(dev).train()
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(2, 512, 8, 8, generator=g)
+    gy = torch.randn(2, 256, 8, 8, generator=g)
+    P = {"aspp." + k: v.clone().requires_grad_(v.is_floating_point() and not k.endswith(("running_mean", "running_var"))) for k, v in st.items()}
+    xr = x.clone().requires_grad_(True)
+    yr = dl.aspp(P, xr, True)
+    yr.backward(gy)
+    xd = x.to(dev).requires_grad_(True)
+    y = mod(xd)
+    y.backward(gy.to(dev))
+
+    def close(a, b, name, tol=1e-3):
+        a, b = a.detach().cpu().double(), b.detach().double()
+        assert float((a - b).abs().max()) <= tol * max(float(b.abs().max()), 1e-6), name
+
+    close(y, yr, "y")
+    close(xd.grad, xr.grad, "dx", 2e-3)
+    for k, p in mod.named_parameters():
+        ref = P["aspp." + k].grad
+        if k.endswith(".bias") and k.startswith("conv") and k != "conv5.bias" and float(ref.abs().max()) < 1e-4:
+            continue
+        close(p.grad, ref, k, 2e-3)
