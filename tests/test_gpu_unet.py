@@ -44,6 +44,7 @@ def test_plain_unet_train_step_matches_reference(pkg, tag):
     ref = gold["grad_norm"]
     rel = np.abs(gn - ref) / (ref + 1e-3 * ref.max())
     assert rel.max() < 2e-2, (names[int(rel.argmax())], gn[int(rel.argmax())], ref[int(rel.argmax())])
+    gmax = max(float(np.abs(v).max()) for kk, v in gold.items() if kk.startswith("grad/") and not kk.endswith("/meta") and v.dtype == np.float32)
     for k, p in net.named_parameters():
         if k.endswith(".bias") and k.split(".")[-2] in ("0", "3"):
             continue            # conv bias in front of a train-mode BatchNorm: analytically zero gradient, rounding noise on both sides
@@ -57,7 +58,7 @@ def test_plain_unet_train_step_matches_reference(pkg, tag):
         # transposed convolutions' biases are sums that cancel to ~1e-3 of their terms): the deep levels of these 2-image
         # tiles normalise 8 .. 32 values per channel, and a ReLU / max-pool decision at a near-tie moves a few elements by ~1e-2
         # (tests/decisions.py explains and, for the Robust U-Net, removes that lottery; measured here: worst element 5.5e-3)
-        scale = float(np.abs(b).max()) + 1e-7 * float(ref.max())
+        scale = max(float(np.abs(b).max()), 1e-3 * gmax)          # tensors 1000x smaller than the largest gradient are rounding-level sums
         err = np.abs(a - b)
         assert err.max() <= 3e-2 * scale, (k, err.max(), scale)
         assert float(np.linalg.norm(a - b)) <= 1e-2 * float(np.linalg.norm(b)) + 1e-4 * float(ref.max()), (k, np.linalg.norm(a - b), np.linalg.norm(b))
