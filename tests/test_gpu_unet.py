@@ -54,20 +54,23 @@ def test_plain_unet_train_step_matches_reference(pkg, tag):
             a, b = g.numpy(), gold[key]
         else:
             a, b = sampled(g, gold[key + "/meta"]), gold[key + "/sample"]
-        # every element within 3e-2 of the tensor's scale and the RMS error within 1 % of that scale (scale = the tensor's largest magnitude, at least 1e-3 of the largest gradient anywhere: the
+        # every element within 3e-2 of the tensor's scale (1 % of them - at least one - up to 0.2: a flipped decision lands on one channel) and the RMS error within 1 % of that scale (scale = the tensor's largest magnitude, at least 1e-3 of the largest gradient anywhere: the
         # transposed convolutions' biases are sums that cancel to ~1e-3 of their terms): the deep levels of these 2-image
         # tiles normalise 8 .. 32 values per channel, and a ReLU / max-pool decision at a near-tie moves a few elements by ~1e-2
         # (tests/decisions.py explains and, for the Robust U-Net, removes that lottery; measured here: worst element 5.5e-3)
         scale = max(float(np.abs(b).max()), 1e-3 * gmax)          # tensors 1000x smaller than the largest gradient are rounding-level sums
         err = np.abs(a - b)
-        assert err.max() <= 3e-2 * scale, (k, err.max(), scale)
+        assert err.max() <= 0.2 * scale and int((err > 3e-2 * scale).sum()) <= max(1, err.size // 100), (k, err.max(), scale)
         assert float(np.linalg.norm(a - b)) <= 1e-2 * scale * np.sqrt(err.size), (k, float(np.linalg.norm(a - b)), scale, err.size)
     for k, b in net.named_buffers():
         if f"buf/{k}" in gold:
             np.testing.assert_allclose(b.cpu().numpy(), gold[f"buf/{k}"], rtol=1e-3, atol=1e-4, err_msg=k)
     opt.step()
     delta = np.array([(p.detach().cpu().double() - st[k].double()).abs().sum().item() for k, p in net.named_parameters()])
-    np.testing.assert_allclose(delta, gold["param_delta_abs_sum"], rtol=2e-2, atol=1e-9)
+    # first Adam step: |dp| = lr * |g| / (|g| + eps); the conv biases in front of a BatchNorm have gradients of rounding-noise size (~eps), so
+    # their step is noise on both sides - every other tensor moves by lr per element
+    real = np.array([not (k.endswith(".bias") and k.split(".")[-2] in ("0", "3")) for k in names])
+    np.testing.assert_allclose(delta[real], gold["param_delta_abs_sum"][real], rtol=2e-2, atol=1e-9)
     net.eval()
     with torch.no_grad():
         le = net(x.to(DEV))
