@@ -92,9 +92,14 @@ def _cached(w, kind, make):
     return val
 
 
+# Measured: reading the data gradients' weights from a cached per-tap transposed copy (modes *_DGRAD_T, n-contiguous staging) instead of the
+# k-contiguous staging of the forward weight changes nothing in the step (421.9 vs 422.2 img/s: those launches are bound by their activation
+# traffic, not by the weight tile) and costs 22 transpose launches (0.33 ms of kernel time) per step, so it is off by default.
+USE_TRANSPOSED_DGRAD = os.environ.get("RUNET_TRANSPOSED_DGRAD", "0") == "1"
+
+
 def transposed_weights(w_hwio):
-    """[taps][cin][cout] -> [taps][cout][cin] (cached per optimizer step): the implicit-GEMM data gradients then stage their weight tile
-    n-contiguous like the forward kernels (49.7 -> ~75 TFLOP/s on the 1x1 / transposed / dilated data gradients)."""
+    """[taps][cin][cout] -> [taps][cout][cin] (cached per optimizer step) for the *_DGRAD_T modes of runet_conv_igemm."""
     kh, kw, cin, cout = w_hwio.shape
 
     def make():
@@ -310,8 +315,12 @@ def conv_dgrad(dy, w_hwio, out=None, dil=1, accumulate=False):
         return wino_conv(dy, wino_weights(w_hwio, dgrad=True), None, out=out, accumulate=accumulate)
     if out is None:
         out = empty_nhwc(n, h, w, cin, dy)
-    _igemm(CONV_DGRAD_T, dy.data_ptr(), ld(dy), transposed_weights(w_hwio).data_ptr(), None, out.data_ptr(), ld(out), n, h, w,
-           cout, cout, cin, kh, kw, dil, int(accumulate))
+    if USE_TRANSPOSED_DGRAD:
+        _igemm(CONV_DGRAD_T, dy.data_ptr(), ld(dy), transposed_weights(w_hwio).data_ptr(), None, out.data_ptr(), ld(out), n, h, w,
+               cout, cout, cin, kh, kw, dil, int(accumulate))
+    else:
+        _igemm(CONV_DGRAD, dy.data_ptr(), ld(dy), w_hwio.data_ptr(), None, out.data_ptr(), ld(out), n, h, w,
+               cout, cout, cin, kh, kw, dil, int(accumulate))
     return out
 
 
@@ -436,8 +445,12 @@ def convt_dgrad(dy, w_hwio, out=None, accumulate=False):
         out = empty_nhwc(n, h, w, cin, dy)
     if _bf16_case(cout, cout):
         return _igemm_bf16(CONVT_DGRAD, dy, w_hwio, None, out, n, h, w, cout, cin, 2, 2, 1, accumulate, True)
-    _igemm(CONVT_DGRAD_T, dy.data_ptr(), ld(dy), transposed_weights(w_hwio).data_ptr(), None, out.data_ptr(), ld(out), n, h, w,
-           cout, cout, cin, 2, 2, 1, int(accumulate))
+    if USE_TRANSPOSED_DGRAD:
+        _igemm(CONVT_DGRAD_T, dy.data_ptr(), ld(dy), transposed_weights(w_hwio).data_ptr(), None, out.data_ptr(), ld(out), n, h, w,
+               cout, cout, cin, 2, 2, 1, int(accumulate))
+    else:
+        _igemm(CONVT_DGRAD, dy.data_ptr(), ld(dy), w_hwio.data_ptr(), None, out.data_ptr(), ld(out), n, h, w,
+               cout, cout, cin, 2, 2, 1, int(accumulate))
     return out
 
 
