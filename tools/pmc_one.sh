@@ -18,7 +18,7 @@ import csv, glob, sys, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(sys.argv[1] + "/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        n = r["Kernel_Name"].replace("void (anonymous namespace)::", "").split("(")[0]
+        n = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
         if n.startswith("at::") or "elementwise" in n or "distribution" in n: continue
         acc[n][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for n, c in acc.items():
