@@ -13,6 +13,17 @@ on a machine without the HIP library; anything that computes raises if
 `csrc/librunet_hip.so` is missing — there is no CPU fallback.
 """
 import importlib as _il
+import os as _os
+import sys as _sys
+
+# The backward pass uses several HIP streams (main chain, weight gradients, gradient all-reduce + RCCL's own): with HIP's default of 4 hardware
+# queues they share queues and serialise on each other's event waits (380 vs 414 img/s).  The variable only counts if it is set before the HIP
+# runtime comes up, so it is set here, when the package is imported - normally long before the first device call.
+_HW_QUEUES_LATE = False
+if "GPU_MAX_HW_QUEUES" not in _os.environ:
+    _os.environ["GPU_MAX_HW_QUEUES"] = "8"
+    _t = _sys.modules.get("torch")
+    _HW_QUEUES_LATE = bool(_t is not None and _t.cuda.is_available() and _t.cuda.is_initialized())
 
 _LAZY = {
     "RobustUNet": "model", "ResidualBlock": "model", "DilatedBlock": "model", "AttentionGate": "model",

@@ -13,14 +13,15 @@ import re
 
 # The backward pass uses several HIP streams (main chain, weight gradients, gradient all-reduce + RCCL's own): with HIP's default of
 # 4 hardware queues they share queues and serialise on each other's event waits.  Only effective if the HIP runtime is not yet initialised.
-_queues_preset = "GPU_MAX_HW_QUEUES" in os.environ
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # normally already done by the package's __init__ (see there)
 
 import torch  # noqa: F401  (first: librunet_hip.so must bind to the HIP runtime that torch already loaded, not a second copy)
 
-if not _queues_preset and torch.cuda.is_available() and torch.cuda.is_initialized():
+from . import _HW_QUEUES_LATE
+
+if _HW_QUEUES_LATE:
     import warnings
-    warnings.warn("the HIP runtime was initialised before this package was imported, so GPU_MAX_HW_QUEUES=8 could not take effect: the "
+    warnings.warn("the HIP runtime was initialised before eusipco-2026-robust-unet_amd was imported, so GPU_MAX_HW_QUEUES=8 could not take effect: the "
                   "weight-gradient / communication streams will share HIP's default 4 hardware queues (about 8 % slower train steps). "
                   "Import the package (or export GPU_MAX_HW_QUEUES=8) before the first CUDA/HIP call.", RuntimeWarning, stacklevel=2)
 
