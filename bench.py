@@ -248,6 +248,8 @@ def run_rank(args):
             dist.barrier()
             torch.cuda.synchronize()
 
+    host_ms = [0.0]
+
     def timed_run(batch, sync_bn, profile, warmup, steps):
         """-> (seconds for `steps` steps: max over ranks, last loss, conv profile or None)"""
         if sync is not None:
@@ -262,6 +264,7 @@ def run_rank(args):
         t0 = time.perf_counter()
         for _ in range(steps):
             loss = step(x, y)
+        host_ms[0] = 1e3 * (time.perf_counter() - t0) / steps      # time the host needed to ENQUEUE a step (diagnostic: host- vs GPU-bound)
         barrier()
         dt = time.perf_counter() - t0
         roof = ops.stop_conv_profile(prof) if prof is not None else None
@@ -275,6 +278,7 @@ def run_rank(args):
             f"{args.dtype}" + (", hipGraph step" if graph else ""))
     want_roof = not args.no_roofline and args.model == "runet" and not graph
     dt, final_loss, roof = timed_run(args.batch, args.sync_bn, want_roof, args.warmup, args.steps)
+    enqueue_ms = host_ms[0]
     if rank == 0:
         log(f"timed region {dt:.3f} s")
 
@@ -311,6 +315,7 @@ def run_rank(args):
         out = {
             "metric": f"train images/sec {name} {args.size}x{args.size} bs{args.batch}/GPU", "value": round(imgs / dt, 2), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+            "host_enqueue_ms_per_step": round(enqueue_ms, 3),
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{name} " + (f"base{args.base} (40.9M params) " if args.model == "runet" else "") +
                                    f"train step, {args.size}x{args.size} RGB+mask tiles, batch {args.batch}/GPU, "

@@ -34,7 +34,17 @@ template <typename T> __device__ __forceinline__ void at4(const T m0, const T m1
     o[0] = m0 + p + r; o[1] = q + 2.f * s; o[2] = p + 4.f * r; o[3] = q + 8.f * s + m5;
 }
 
-struct W4Geom { int n_img, H, W, TY, TX; long T; };
+// A convolution with dilation D over an H x W image is D*D independent dilation-1 convolutions over its (H/D) x (W/D) sub-images
+// (rows oy, oy+D, ... and columns ox, ox+D, ...): the padding D of the full image is the padding 1 of each sub-image.  The transform
+// kernels therefore see n_img*D*D "images" of H x W = sub-image size and only their addressing knows about D (pix()).
+struct W4Geom { int n_img, H, W, TY, TX, D, WF; long T, img_px; };
+
+__device__ __forceinline__ long pix(const W4Geom& g, int n, int ih, int iw) {        // pixel index in the full NHWC tensor
+    if (g.D == 1) return ((long)n * g.H + ih) * g.W + iw;
+    const int dd = g.D * g.D;
+    const int nf = n / dd, o = n - nf * dd, oy = o / g.D, ox = o - oy * g.D;
+    return (long)nf * g.img_px + (long)(ih * g.D + oy) * g.WF + (iw * g.D + ox);
+}
 
 // MODE 0: src = conv input (or dy for the data gradient), 6x6 patch at (4ty-1, 4tx-1);  MODE 1: src = dy, 4x4 tile at (4ty, 4tx)
 template <int MODE>
@@ -57,7 +67,7 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restric
             for (int j = 0; j < 6; ++j) {
                 const int ih = h0 + i, iw = w0 + j;
                 const bool ok = (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
-                const long off = ok ? (((long)n * g.H + ih) * g.W + iw) * ld + c : 0;
+                const long off = ok ? pix(g, n, ih, iw) * ld + c : 0;
                 const f32x2 v = *reinterpret_cast<const f32x2*>(src + off);
                 d[i][j] = ok ? v : f32x2{0.f, 0.f};
             }
@@ -67,11 +77,12 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restric
         for (int i = 0; i < 6; ++i) bt6(d[i][0], d[i][1], d[i][2], d[i][3], d[i][4], d[i][5]);
     } else {
         f32x2 y[4][4], t[6][4];
-        const float* base = src + (((long)n * g.H + 4 * ty) * g.W + 4 * tx) * ld + c;
+        const float* base = src + pix(g, n, 4 * ty, 4 * tx) * ld + c;
+        const long rs = (long)g.D * g.WF * ld, ps = (long)g.D * ld;          // row / pixel stride inside the sub-image
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) y[i][j] = *reinterpret_cast<const f32x2*>(base + ((long)i * g.W + j) * ld);
+            for (int j = 0; j < 4; ++j) y[i][j] = *reinterpret_cast<const f32x2*>(base + i * rs + j * ps);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             f32x2 z[6];
@@ -115,14 +126,15 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
     }
     f32x2 bv = {0.f, 0.f};
     if (bias) bv = *reinterpret_cast<const f32x2*>(bias + c);
-    float* dst = y + (((long)n * g.H + 4 * ty) * g.W + 4 * tx) * ldy + c;
+    float* dst = y + pix(g, n, 4 * ty, 4 * tx) * ldy + c;
+    const long rs = (long)g.D * g.WF * ldy, ps = (long)g.D * ldy;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         f32x2 o[4];
         at4(s[i][0], s[i][1], s[i][2], s[i][3], s[i][4], s[i][5], o);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            float* p = dst + ((long)i * g.W + j) * ldy;
+            float* p = dst + i * rs + j * ps;
             f32x2 v = o[j] + bv;
             if (accumulate) v += *reinterpret_cast<const f32x2*>(p);
             *reinterpret_cast<f32x2*>(p) = v;
@@ -196,11 +208,13 @@ __global__ __launch_bounds__(256) void wino4_wgrad_out_kernel(const float* __res
     }
 }
 
-W4Geom geom(int n_img, int h, int w) {
+W4Geom geom(int n_img, int h, int w, int dil) {
     W4Geom g{};
-    g.n_img = n_img; g.H = h; g.W = w; g.TY = h / 4; g.TX = w / 4; g.T = (long)n_img * g.TY * g.TX;
+    g.D = dil; g.WF = w; g.img_px = (long)h * w;
+    g.n_img = n_img * dil * dil; g.H = h / dil; g.W = w / dil; g.TY = g.H / 4; g.TX = g.W / 4; g.T = (long)g.n_img * g.TY * g.TX;
     return g;
 }
+bool dil_ok(int h, int w, int dil) { return dil >= 1 && dil <= 8 && h % dil == 0 && w % dil == 0; }
 
 // rows (tiles) per split of the weight-gradient GEMMs: enough splits for ~512 blocks, at least 64 tiles each, 16-aligned
 int wgrad_rows_per_split(long T, int cin, int cout) {
@@ -230,19 +244,20 @@ extern "C" int runet_wino4_weights(const float* w_hwio, float* U, int cin, int c
 
 // The three stages of runet_wino4_conv / runet_wino4_wgrad as separate entry points (profiling, reuse of V between forward and
 // weight gradient).  mode 0: V[36][T][c] = B^T d B of the 6x6 patches of src;  mode 1: Z[36][T][c] = A dY A^T of the 4x4 tiles.
-extern "C" int runet_wino4_input(const float* src, int ld, int c, int n_img, int h, int w, int mode, float* V, void* stream) {
-    RUNET_REQUIRE(src && V && runet_wino4_supported(h, w, 16, 4) && c > 0 && c % 2 == 0 && ld >= c && ld % 2 == 0, "bad arguments");
+extern "C" int runet_wino4_input(const float* src, int ld, int c, int n_img, int h, int w, int dil, int mode, float* V, void* stream) {
+    RUNET_REQUIRE(src && V && dil_ok(h, w, dil) && runet_wino4_supported(h / dil, w / dil, 16, 4) && c > 0 && c % 2 == 0 && ld >= c && ld % 2 == 0, "bad arguments");
     RUNET_REQUIRE(((uintptr_t)src % 8) == 0 && ((uintptr_t)V % 8) == 0 && (mode == 0 || mode == 1), "alignment / mode");
-    const W4Geom g = geom(n_img, h, w);
+    const W4Geom g = geom(n_img, h, w, dil);
     if (mode == 0) hipLaunchKernelGGL(wino4_input_kernel<0>, dim3(cdiv(g.T * (c / 2), 256)), dim3(256), 0, (hipStream_t)stream, src, ld, c, g, V);
     else hipLaunchKernelGGL(wino4_input_kernel<1>, dim3(cdiv(g.T * (c / 2), 256)), dim3(256), 0, (hipStream_t)stream, src, ld, c, g, V);
     RUNET_CHECK_LAUNCH();
 }
 
-extern "C" int runet_wino4_output(const float* M, int n, int n_img, int h, int w, const float* bias, float* y, int ldy, int accumulate, void* stream) {
-    RUNET_REQUIRE(M && y && runet_wino4_supported(h, w, 16, 4) && n > 0 && n % 2 == 0 && ldy >= n && ldy % 2 == 0, "bad arguments");
+extern "C" int runet_wino4_output(const float* M, int n, int n_img, int h, int w, int dil, const float* bias, float* y, int ldy, int accumulate,
+                                  void* stream) {
+    RUNET_REQUIRE(M && y && dil_ok(h, w, dil) && runet_wino4_supported(h / dil, w / dil, 16, 4) && n > 0 && n % 2 == 0 && ldy >= n && ldy % 2 == 0, "bad arguments");
     RUNET_REQUIRE(((uintptr_t)M % 8) == 0 && ((uintptr_t)y % 8) == 0 && (!bias || ((uintptr_t)bias % 8) == 0), "alignment");
-    const W4Geom g = geom(n_img, h, w);
+    const W4Geom g = geom(n_img, h, w, dil);
     hipLaunchKernelGGL(wino4_output_kernel, dim3(cdiv(g.T * (n / 2), 256)), dim3(256), 0, (hipStream_t)stream, M, n, g, bias, y, ldy, accumulate);
     RUNET_CHECK_LAUNCH();
 }
@@ -259,14 +274,15 @@ extern "C" int runet_wino4_wgrad_rows_per_split(int n_img, int h, int w, int cin
 }
 
 extern "C" int runet_wino4_conv(const float* x, int ldx, const float* U, const float* bias, float* y, int ldy, int n_img, int h, int w, int k, int n,
-                                int accumulate, float* workspace, long workspace_floats, void* stream) {
+                                int dil, int accumulate, float* workspace, long workspace_floats, void* stream) {
     RUNET_REQUIRE(x && U && y && workspace, "null pointer");
-    RUNET_REQUIRE(runet_wino4_supported(h, w, k, n), "shape not supported by the F(4x4,3x3) path (H, W multiples of 4; K, N multiples of 4)");
+    RUNET_REQUIRE(dil_ok(h, w, dil) && runet_wino4_supported(h / dil, w / dil, k, n),
+                  "shape not supported by the F(4x4,3x3) path (H/dil, W/dil multiples of 4; K, N multiples of 4)");
     RUNET_REQUIRE(ldx >= k && ldx % 2 == 0 && ldy >= n && ldy % 2 == 0, "pixel strides must be even and cover the channels");
     RUNET_REQUIRE(((uintptr_t)x % 8) == 0 && ((uintptr_t)y % 8) == 0 && ((uintptr_t)U % 16) == 0 && ((uintptr_t)workspace % 16) == 0 &&
                   (!bias || ((uintptr_t)bias % 8) == 0), "alignment");
     RUNET_REQUIRE(workspace_floats >= runet_wino4_workspace_floats(n_img, h, w, k, n), "workspace too small (runet_wino4_workspace_floats)");
-    const W4Geom g = geom(n_img, h, w);
+    const W4Geom g = geom(n_img, h, w, dil);
     hipStream_t st = (hipStream_t)stream;
     float* V = workspace;
     float* M = workspace + 36L * g.T * k;
@@ -283,13 +299,13 @@ extern "C" long runet_wino4_wgrad_workspace_floats(int n_img, int h, int w, int 
 }
 
 extern "C" int runet_wino4_wgrad(const float* x, int ldx, const float* dy, int ldy, float* dw, float* workspace, long workspace_floats, int n_img,
-                                 int h, int w, int cin, int cout, void* stream) {
+                                 int h, int w, int cin, int cout, int dil, void* stream) {
     RUNET_REQUIRE(x && dy && dw && workspace, "null pointer");
-    RUNET_REQUIRE(runet_wino4_supported(h, w, cin, cout) && cout >= 16, "shape not supported by the F(4x4,3x3) weight gradient");
+    RUNET_REQUIRE(dil_ok(h, w, dil) && runet_wino4_supported(h / dil, w / dil, cin, cout) && cout >= 16, "shape not supported by the F(4x4,3x3) weight gradient");
     RUNET_REQUIRE(ldx >= cin && ldx % 2 == 0 && ldy >= cout && ldy % 2 == 0, "pixel strides must be even and cover the channels");
     RUNET_REQUIRE(((uintptr_t)x % 8) == 0 && ((uintptr_t)dy % 8) == 0 && ((uintptr_t)workspace % 16) == 0, "alignment");
     RUNET_REQUIRE(workspace_floats >= runet_wino4_wgrad_workspace_floats(n_img, h, w, cin, cout), "workspace too small (runet_wino4_wgrad_workspace_floats)");
-    const W4Geom g = geom(n_img, h, w);
+    const W4Geom g = geom(n_img, h, w, dil);
     hipStream_t st = (hipStream_t)stream;
     float* V = workspace;
     float* Z = V + 36L * g.T * cin;

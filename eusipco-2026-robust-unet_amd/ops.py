@@ -243,10 +243,17 @@ def _wino_case(h, w, kh, dil, k, n, cin_w, n_img=1, ldx=0, ldy=0):
 USE_WINOGRAD4 = USE_WINOGRAD and os.environ.get("RUNET_NO_WINOGRAD4", "0") != "1"
 
 
+USE_WINOGRAD4_DILATED = USE_WINOGRAD4 and os.environ.get("RUNET_NO_WINOGRAD4_DILATED", "0") != "1"
+
+
 def _wino4_case(h, w, kh, dil, k, n, cin_w):
-    """Deep layers (>= 256 channels on one side, <= 128x128 pixels): unfused F(4x4,3x3) beats the fused F(2x2) kernel (tools/bench_conv.py)."""
-    return (USE_WINOGRAD4 and kh == 3 and dil == 1 and cin_w == k and max(k, n) >= 256 and min(k, n) >= 128 and h * w <= 128 * 128
-            and bool(lib.runet_wino4_supported(h, w, k, n)))
+    """Deep layers (>= 256 channels on one side, <= 128x128 pixels): unfused F(4x4,3x3) beats the fused F(2x2) kernel (tools/bench_conv.py).
+    Dilated 3x3 convolutions (the bottleneck's DilatedBlock, dilation 2 and 4) take the same path as dil*dil dilation-1 convolutions over
+    the sub-images of every image (csrc/conv_winograd4.hip pix()): 4x fewer multiplies than the implicit GEMM they used before."""
+    if dil != 1 and not (USE_WINOGRAD4_DILATED and h % dil == 0 and w % dil == 0):
+        return False
+    return (USE_WINOGRAD4 and kh == 3 and cin_w == k and max(k, n) >= 256 and min(k, n) >= 128 and h * w <= 128 * 128
+            and bool(lib.runet_wino4_supported(h // dil, w // dil, k, n)))
 
 
 def conv_fwd(x, w_hwio, bias=None, out=None, dil=1, accumulate=False, keep_v=None):
@@ -257,7 +264,7 @@ def conv_fwd(x, w_hwio, bias=None, out=None, dil=1, accumulate=False, keep_v=Non
             out = empty_nhwc(n, h, w, cout, x)
         return _igemm_bf16(CONV_FWD, x, w_hwio, bias, out, n, h, w, cin, cout, kh, kw, dil, accumulate, False)
     if _wino4_case(h, w, kh, dil, cin, cout, cin_w):
-        return wino4_conv(x, wino4_weights(w_hwio), bias, out=out, accumulate=accumulate, keep_v=keep_v)
+        return wino4_conv(x, wino4_weights(w_hwio), bias, out=out, accumulate=accumulate, keep_v=keep_v, dil=dil)
     if _wino_case(h, w, kh, dil, cin, cout, cin_w, n, ld(x), ld(out) if out is not None else cout):
         return wino_conv(x, wino_weights(w_hwio), bias, out=out, accumulate=accumulate)
     if out is None:
@@ -310,7 +317,7 @@ def conv_dgrad(dy, w_hwio, out=None, dil=1, accumulate=False):
             out = empty_nhwc(n, h, w, cin, dy)
         return _igemm_bf16(CONV_DGRAD, dy, w_hwio, None, out, n, h, w, cout, cin, kh, kw, dil, accumulate, True)
     if _wino4_case(h, w, kh, dil, cout, cin, cout):
-        return wino4_conv(dy, wino4_weights(w_hwio, dgrad=True), None, out=out, accumulate=accumulate)
+        return wino4_conv(dy, wino4_weights(w_hwio, dgrad=True), None, out=out, accumulate=accumulate, dil=dil)
     if _wino_case(h, w, kh, dil, cout, cin, cout, n, ld(dy), ld(out) if out is not None else cin):
         return wino_conv(dy, wino_weights(w_hwio, dgrad=True), None, out=out, accumulate=accumulate)
     if out is None:
@@ -385,7 +392,7 @@ def _conv_wgrad(x, dy, kh, kw, cin_w=None, dil=1, out=None, v=None):
     if _bf16_case(cin, cin_w):
         return _wgrad_bf16(x, dy, out, n, h, w, cin, cout, kh, kw, dil, 0)
     if _wino4_case(h, w, kh, dil, cin, cout, cin_w) and cout >= 16:
-        return wino4_wgrad(x, dy, out=out, v=v)
+        return wino4_wgrad(x, dy, out=out, v=v, dil=dil)
     prof = _PROFILE is not None
     if prof:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -681,7 +688,7 @@ def wino4_weights(w_hwio, dgrad=False):
     return _cached(w_hwio, "wino4d" if dgrad else "wino4", make)
 
 
-def wino4_conv(x, U, bias=None, out=None, accumulate=False, keep_v=None):
+def wino4_conv(x, U, bias=None, out=None, accumulate=False, keep_v=None, dil=1):
     """keep_v: dict that receives {"V": transformed input [36*T*K]} - the weight gradient of the same convolution reuses it
     (conv_wgrad(..., v=...)) instead of transforming x again."""
     n, h, w, k = x.shape
@@ -692,7 +699,7 @@ def wino4_conv(x, U, bias=None, out=None, accumulate=False, keep_v=None):
     t = n * (h // 4) * (w // 4)
     if _PROFILE is None and keep_v is None:
         ws = _workspace4(lib.runet_wino4_workspace_floats(n, h, w, k, nn_), x.device)
-        check(lib.runet_wino4_conv(x.data_ptr(), ld(x), U.data_ptr(), bp, out.data_ptr(), ld(out), n, h, w, k, nn_, int(accumulate), ws.data_ptr(),
+        check(lib.runet_wino4_conv(x.data_ptr(), ld(x), U.data_ptr(), bp, out.data_ptr(), ld(out), n, h, w, k, nn_, dil, int(accumulate), ws.data_ptr(),
                                    ws.numel(), stream()))
         return out
     # the same three kernels through their own entry points (V kept for the backward pass / HIP events around the position-GEMM alone)
@@ -703,7 +710,7 @@ def wino4_conv(x, U, bias=None, out=None, accumulate=False, keep_v=None):
     else:
         ws = _workspace4(36 * t * (k + nn_), x.device)
         V, M = ws.data_ptr(), ws.data_ptr() + 4 * 36 * t * k
-    check(lib.runet_wino4_input(x.data_ptr(), ld(x), k, n, h, w, 0, V, stream()))
+    check(lib.runet_wino4_input(x.data_ptr(), ld(x), k, n, h, w, dil, 0, V, stream()))
     if _PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -712,11 +719,11 @@ def wino4_conv(x, U, bias=None, out=None, accumulate=False, keep_v=None):
         e1.record()
         fl = 2.0 * 36 * t * k * nn_          # the position-GEMMs' own FLOPs; the convolution they implement is 4x that in direct-conv FLOPs
         _PROFILE.append((lib.runet_gemm_batched_kernel_name(36, t, k, nn_).decode(), 4.0 * fl, fl, e0, e1))
-    check(lib.runet_wino4_output(M, nn_, n, h, w, bp, out.data_ptr(), ld(out), int(accumulate), stream()))
+    check(lib.runet_wino4_output(M, nn_, n, h, w, dil, bp, out.data_ptr(), ld(out), int(accumulate), stream()))
     return out
 
 
-def wino4_wgrad(x, dy, out=None, v=None):
+def wino4_wgrad(x, dy, out=None, v=None, dil=1):
     """v: the forward pass's transformed input (wino4_conv(keep_v=...)) - skips the B^T d B pass over x."""
     n, h, w, cin = x.shape
     cout = dy.shape[3]
@@ -724,7 +731,7 @@ def wino4_wgrad(x, dy, out=None, v=None):
         out = torch.empty((3, 3, cin, cout), device=x.device, dtype=torch.float32)
     ws = _workspace4(lib.runet_wino4_wgrad_workspace_floats(n, h, w, cin, cout), x.device)
     if _PROFILE is None and v is None:
-        check(lib.runet_wino4_wgrad(x.data_ptr(), ld(x), dy.data_ptr(), ld(dy), out.data_ptr(), ws.data_ptr(), ws.numel(), n, h, w, cin, cout, stream()))
+        check(lib.runet_wino4_wgrad(x.data_ptr(), ld(x), dy.data_ptr(), ld(dy), out.data_ptr(), ws.data_ptr(), ws.numel(), n, h, w, cin, cout, dil, stream()))
         return out
     t = n * (h // 4) * (w // 4)
     V = ws.data_ptr()
@@ -732,11 +739,11 @@ def wino4_wgrad(x, dy, out=None, v=None):
     dU = Z + 4 * 36 * t * cout
     rps = lib.runet_wino4_wgrad_rows_per_split(n, h, w, cin, cout)
     if v is None:
-        check(lib.runet_wino4_input(x.data_ptr(), ld(x), cin, n, h, w, 0, V, stream()))
+        check(lib.runet_wino4_input(x.data_ptr(), ld(x), cin, n, h, w, dil, 0, V, stream()))
     else:
         assert v.numel() == 36 * t * cin
         V = v.data_ptr()
-    check(lib.runet_wino4_input(dy.data_ptr(), ld(dy), cout, n, h, w, 1, Z, stream()))
+    check(lib.runet_wino4_input(dy.data_ptr(), ld(dy), cout, n, h, w, dil, 1, Z, stream()))
     if _PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

@@ -199,23 +199,25 @@ const char* runet_gemm_batched_kernel_name(int batch, int rows, int k, int n);
 
 /* ---- Winograd F(4x4,3x3), unfused, for the deep 3x3 convolutions (Main_Final.py:157,159 at >= 256 channels) and their autograd ----
  * U [36][K][N] from runet_wino4_weights (dgrad != 0: rotated filter, K = cout, N = cin).  conv: x [n,h,w,K] -> y [n,h,w,N] ('same'), H, W % 4 == 0.
+ * dil >= 1 (padding = dil: the bottleneck's DilatedBlock, Main_Final.py:207-208): the dilated convolution is run as dil*dil independent
+ * dilation-1 convolutions over the (h/dil) x (w/dil) sub-images of every image, so (h/dil) % 4 == 0 and (w/dil) % 4 == 0 are required.
  * workspace: runet_wino4_workspace_floats / runet_wino4_wgrad_workspace_floats floats, 16-byte aligned. */
 int runet_wino4_supported(int h, int w, int k, int n);
 long runet_wino4_workspace_floats(int n_img, int h, int w, int k, int n);
 int runet_wino4_weights(const float* w_hwio, float* U, int cin, int cout, int dgrad, void* stream);
 int runet_wino4_conv(const float* x, int ldx, const float* U, const float* bias, float* y, int ldy, int n_img, int h, int w, int k, int n,
-                     int accumulate, float* workspace, long workspace_floats, void* stream);
+                     int dil, int accumulate, float* workspace, long workspace_floats, void* stream);
 /* the stages of the two composites below, one kernel each (T = n_img*(h/4)*(w/4) tiles):
  *   runet_wino4_input  mode 0: V[36][T][c] = B^T d B (6x6 patches of src, stride 4, 1-pixel halo); mode 1: Z[36][T][c] = A dY A^T (4x4 tiles)
  *   runet_gemm_batched / runet_gemm_tn_batched: the 36 position-GEMMs
  *   runet_wino4_output: y = A^T M A (+bias, +y);  runet_wino4_wgrad_output: dw[3][3][cin][cout] = G^T (sum_splits dU[split][36][cin][cout]) G */
-int runet_wino4_input(const float* src, int ld, int c, int n_img, int h, int w, int mode, float* V, void* stream);
-int runet_wino4_output(const float* M, int n, int n_img, int h, int w, const float* bias, float* y, int ldy, int accumulate, void* stream);
+int runet_wino4_input(const float* src, int ld, int c, int n_img, int h, int w, int dil, int mode, float* V, void* stream);
+int runet_wino4_output(const float* M, int n, int n_img, int h, int w, int dil, const float* bias, float* y, int ldy, int accumulate, void* stream);
 int runet_wino4_wgrad_output(const float* dU, int splits, int cin, int cout, float* dw, void* stream);
 int runet_wino4_wgrad_rows_per_split(int n_img, int h, int w, int cin, int cout);
 long runet_wino4_wgrad_workspace_floats(int n_img, int h, int w, int cin, int cout);
 int runet_wino4_wgrad(const float* x, int ldx, const float* dy, int ldy, float* dw, float* workspace, long workspace_floats, int n_img, int h, int w,
-                      int cin, int cout, void* stream);
+                      int cin, int cout, int dil, void* stream);
 
 /* ---- DeepLabV3+ baseline (Main_Final.py:325-433): the same implicit-GEMM kernels with general geometry ----
  * runet_conv2d_general: Conv2d(kh x kw <= 7x7, stride 1|2, padding, dilation).  mode RUNET_CONV_FWD: x [n,hin,win,cin] -> y [n,ho,wo,cout],

@@ -40,6 +40,8 @@ CASES = [
     (2, 8, 8, 256, 8, 1, 1),         # 1x1, cout 8
     (1, 64, 64, 64, 64, 3, 1),       # 256x64 tile path (P = 4096 < threshold) and more
     (2, 256, 256, 16, 64, 3, 1),     # large M: 256-row tiles
+    (2, 16, 16, 256, 128, 3, 2),     # DilatedBlock shapes: dilation through the F(4x4) sub-image path when Winograd is on
+    (1, 16, 32, 128, 256, 3, 4),
 ]
 
 
@@ -151,9 +153,12 @@ def test_winograd_fwd_and_dgrad(n, h, w, cin, cout):
     assert float(buf[..., :8].min()) == 3.0 and float(buf[..., :8].max()) == 3.0
 
 
-@pytest.mark.parametrize("n,h,w,cin,cout", [(2, 8, 8, 32, 48), (3, 12, 20, 64, 32), (2, 16, 16, 256, 128), (1, 4, 4, 128, 256), (16, 16, 16, 128, 128)])
-def test_winograd_f4_matches_torch(n, h, w, cin, cout):
-    """Unfused F(4x4,3x3): forward (+bias, +accumulate), data gradient and weight gradient against torch CPU conv2d."""
+@pytest.mark.parametrize("n,h,w,cin,cout,dil", [(2, 8, 8, 32, 48, 1), (3, 12, 20, 64, 32, 1), (2, 16, 16, 256, 128, 1), (1, 4, 4, 128, 256, 1),
+                                                (16, 16, 16, 128, 128, 1), (2, 16, 16, 64, 32, 2), (2, 16, 16, 32, 64, 4), (3, 8, 24, 16, 16, 2),
+                                                (1, 32, 16, 128, 64, 4), (2, 16, 16, 512, 256, 2)])
+def test_winograd_f4_matches_torch(n, h, w, cin, cout, dil):
+    """Unfused F(4x4,3x3): forward (+bias, +accumulate), data gradient and weight gradient against torch CPU conv2d.  dil > 1: the
+    dilated convolution as dil*dil dilation-1 convolutions over the sub-images (the DilatedBlock's conv3 / conv4, Main_Final.py:207-208)."""
     import importlib
     import torch.nn.functional as F
     ops = importlib.import_module("eusipco-2026-robust-unet_amd.ops")
@@ -161,33 +166,36 @@ def test_winograd_f4_matches_torch(n, h, w, cin, cout):
     x = torch.randn(n, cin, h, w, generator=g, requires_grad=True)
     wt = (torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5).requires_grad_(True)
     b = torch.randn(cout, generator=g)
-    y = F.conv2d(x, wt, b, 1, 1)
+    y = F.conv2d(x, wt, b, 1, dil, dil)
     dy = torch.randn(y.shape, generator=g)
     y.backward(dy)
     dev = "cuda:0"
     xd = x.detach().permute(0, 2, 3, 1).contiguous().to(dev)
     dyd = dy.permute(0, 2, 3, 1).contiguous().to(dev)
     wd = wt.detach().permute(2, 3, 1, 0).contiguous().to(dev)
-    assert ops.wino4_ok(h, w, cin, cout)
+    assert ops.wino4_ok(h // dil, w // dil, cin, cout)
 
     def close(got, ref, tol, msg):
         ref = ref.detach().numpy()
         np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=tol, atol=tol * float(np.abs(ref).max()), err_msg=msg)
 
     U, Ud = ops.wino4_weights(wd), ops.wino4_weights(wd, dgrad=True)
-    got = ops.wino4_conv(xd, U, b.to(dev))
+    got = ops.wino4_conv(xd, U, b.to(dev), dil=dil)
     close(got.permute(0, 3, 1, 2), y, 2e-4, "fwd")
     base = torch.randn(n, h, w, cout, generator=g).to(dev)
     acc = base.clone()
-    ops.wino4_conv(xd, U, None, out=acc, accumulate=True)
+    ops.wino4_conv(xd, U, None, out=acc, accumulate=True, dil=dil)
     close((acc - base).permute(0, 3, 1, 2), y - b.view(1, -1, 1, 1), 5e-4, "fwd accumulate")
-    close(ops.wino4_conv(dyd, Ud).permute(0, 3, 1, 2), x.grad, 2e-4, "dgrad")
-    close(ops.wino4_wgrad(xd, dyd).permute(3, 2, 0, 1), wt.grad, 5e-4, "wgrad")
+    close(ops.wino4_conv(dyd, Ud, dil=dil).permute(0, 3, 1, 2), x.grad, 2e-4, "dgrad")
+    close(ops.wino4_wgrad(xd, dyd, dil=dil).permute(3, 2, 0, 1), wt.grad, 5e-4, "wgrad")
+    keep = {}
+    ops.wino4_conv(xd, U, b.to(dev), keep_v=keep, dil=dil)             # the forward's transformed input reused by the weight gradient
+    close(ops.wino4_wgrad(xd, dyd, v=keep["V"], dil=dil).permute(3, 2, 0, 1), wt.grad, 5e-4, "wgrad from kept V")
     # channel-slice views (concat buffers): pixel stride > channels
     big = torch.zeros(n, h, w, cin + 32, device=dev)
     big[..., 16:16 + cin] = xd
     outb = torch.zeros(n, h, w, cout + 8, device=dev)
-    ops.wino4_conv(big[..., 16:16 + cin], U, b.to(dev), out=outb[..., 4:4 + cout])
+    ops.wino4_conv(big[..., 16:16 + cin], U, b.to(dev), out=outb[..., 4:4 + cout], dil=dil)
     close(outb[..., 4:4 + cout].permute(0, 3, 1, 2), y, 2e-4, "fwd strided")
     assert float(outb[..., :4].abs().max()) == 0.0 and float(outb[..., 4 + cout:].abs().max()) == 0.0
 
