@@ -196,13 +196,18 @@ def rb_forward(x, p: RBParams, training, mask=None, save=True, stats_hook=None):
     hw, P = h * w, n * h * w
     st = ops.stream()
     sm = Small(x.device)
+    kv1, kv2 = ({}, {}) if save else (None, None)      # F(4x4) layers: the transformed inputs are kept for the weight gradients
+    t1 = None
     if p.ws is not None:
-        r = ops.conv_fwd(x, p.ws)
+        if ops._stem_case(x.shape[3], p.cin_w, c, 3) and p.ws.shape[2] == p.cin_w:
+            t1, r = ops.stem_conv(x, p.w1, p.ws)       # RGB stem: conv1 and the shortcut convolution in one launch
+        else:
+            r = ops.conv_fwd(x, p.ws)
         ss, hs, mean_s, invstd_s, _ = bn_coeff(r, p.bns, training, sm, stats_hook=stats_hook)
     else:
         r, ss, hs, mean_s, invstd_s = x, None, None, None, None
-    kv1, kv2 = ({}, {}) if save else (None, None)      # F(4x4) layers: the transformed inputs are kept for the weight gradients
-    t1 = ops.conv_fwd(x, p.w1, keep_v=kv1)
+    if t1 is None:
+        t1 = ops.conv_fwd(x, p.w1, keep_v=kv1)
     s1, h1, mean1, invstd1, _ = bn_coeff(t1, p.bn1, training, sm, stats_hook=stats_hook)
     use_mask = mask if training else None
     a1 = bn_apply(t1, s1, h1, use_mask, relu=True)

@@ -256,6 +256,25 @@ def _wino4_case(h, w, kh, dil, k, n, cin_w):
             and bool(lib.runet_wino4_supported(h // dil, w // dil, k, n)))
 
 
+USE_STEM_KERNELS = os.environ.get("RUNET_NO_STEM_KERNELS", "0") != "1"
+
+
+def _stem_case(cin, cin_w, cout, kh, dil=1):
+    """The RGB stem (1..3 real channels in a 4-channel NHWC tensor): csrc/conv_stem.hip instead of the general kernels."""
+    return USE_STEM_KERNELS and cin == 4 and kh in (1, 3) and dil == 1 and bool(lib.runet_stem_supported(cin_w, cout))
+
+
+def stem_conv(x, w3, w1=None):
+    """x [N,H,W,4] (RGB + zero) -> (conv3x3(x, w3), conv1x1(x, w1) or None) in one launch; w3 [3,3,cin_w,C], w1 [1,1,cin_w,C]."""
+    n, h, w, _ = x.shape
+    _, _, cin_w, cout = w3.shape
+    y3 = empty_nhwc(n, h, w, cout, x)
+    y1 = empty_nhwc(n, h, w, cout, x) if w1 is not None else None
+    check(lib.runet_stem_conv(x.data_ptr(), ld(x), w3.data_ptr(), w1.data_ptr() if w1 is not None else None, y3.data_ptr(), ld(y3),
+                              y1.data_ptr() if y1 is not None else None, ld(y1) if y1 is not None else 0, n, h, w, cin_w, cout, stream()))
+    return y3, y1
+
+
 def conv_fwd(x, w_hwio, bias=None, out=None, dil=1, accumulate=False, keep_v=None):
     n, h, w, cin = x.shape
     kh, kw, cin_w, cout = w_hwio.shape
@@ -393,6 +412,11 @@ def _conv_wgrad(x, dy, kh, kw, cin_w=None, dil=1, out=None, v=None):
         return _wgrad_bf16(x, dy, out, n, h, w, cin, cout, kh, kw, dil, 0)
     if _wino4_case(h, w, kh, dil, cin, cout, cin_w) and cout >= 16:
         return wino4_wgrad(x, dy, out=out, v=v, dil=dil)
+    if _stem_case(cin, cin_w, cout, kh, dil):
+        ws = workspace(lib.runet_stem_wgrad_workspace_floats(n, h, w, cin_w, cout, kh), x.device)
+        check(lib.runet_stem_wgrad(x.data_ptr(), ld(x), dy.data_ptr(), ld(dy), out.data_ptr(), ws.data_ptr(), ws.numel(), n, h, w, cin_w, cout, kh,
+                                   stream()))
+        return out
     prof = _PROFILE is not None
     if prof:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

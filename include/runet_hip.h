@@ -219,6 +219,18 @@ long runet_wino4_wgrad_workspace_floats(int n_img, int h, int w, int cin, int co
 int runet_wino4_wgrad(const float* x, int ldx, const float* dy, int ldy, float* dw, float* workspace, long workspace_floats, int n_img, int h, int w,
                       int cin, int cout, int dil, void* stream);
 
+/* ---- the RGB stem (Main_Final.py:157,172 with in_channels = 3; `inc` :235): 1..3 real input channels in an NHWC tensor padded to 4 ----
+ * runet_stem_conv: y3 = conv3x3(x, w3 [3][3][cin_w][cout], padding 1) and, if w1 != NULL, y1 = conv1x1(x, w1 [cin_w][cout]) (the first
+ * ResidualBlock's shortcut) in ONE launch: x is read once, both filters form one register-resident B matrix.  No bias (the block's
+ * convolutions have none).  runet_stem_wgrad: dw [k][k][cin_w][cout] of either convolution (ksize 3 or 1) with the pixels as the MFMA
+ * contraction; workspace: runet_stem_wgrad_workspace_floats floats.  cout 32 or 64 (runet_stem_supported). */
+int runet_stem_supported(int cin_w, int cout);
+int runet_stem_conv(const float* x, int ldx, const float* w3, const float* w1, float* y3, int ldy3, float* y1, int ldy1, int n_img,
+                    int h, int w, int cin_w, int cout, void* stream);
+long runet_stem_wgrad_workspace_floats(int n_img, int h, int w, int cin_w, int cout, int ksize);
+int runet_stem_wgrad(const float* x, int ldx, const float* dy, int ldy, float* dw, float* workspace, long workspace_floats, int n_img,
+                     int h, int w, int cin_w, int cout, int ksize, void* stream);
+
 /* ---- DeepLabV3+ baseline (Main_Final.py:325-433): the same implicit-GEMM kernels with general geometry ----
  * runet_conv2d_general: Conv2d(kh x kw <= 7x7, stride 1|2, padding, dilation).  mode RUNET_CONV_FWD: x [n,hin,win,cin] -> y [n,ho,wo,cout],
  * w [kh,kw,cin_w,cout];  mode RUNET_CONV_DGRAD: x := dy [n,ho,wo,cin(=conv Cout)] -> y := dx [n,hin,win,cout(=conv Cin)], w [kh,kw,cout,cin].

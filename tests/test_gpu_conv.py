@@ -97,6 +97,40 @@ def test_conv_stem_rgb_padded_to_4():
     close(dw.permute(3, 2, 0, 1), wr.grad, tol=5e-4)
 
 
+@pytest.mark.parametrize("n,h,w,cin_w,cout", [(2, 32, 32, 3, 64), (1, 24, 40, 3, 32), (3, 8, 72, 1, 64), (2, 16, 16, 2, 32), (2, 256, 256, 3, 64)])
+def test_stem_kernels(n, h, w, cin_w, cout):
+    """csrc/conv_stem.hip: conv3x3 + the 1x1 shortcut of the RGB stem in one launch, and both weight gradients (pixels as the MFMA
+    contraction), against torch CPU conv2d; tiles that overhang the image, 1..3 real channels, garbage in the padding channel."""
+    ops = _ops()
+    dev = torch.device("cuda:0")
+    x = rnd((n, cin_w, h, w), 11)
+    w3 = rnd((cout, cin_w, 3, 3), 12, std=0.3)
+    w1 = rnd((cout, cin_w, 1, 1), 13, std=0.5)
+    g3, g1 = rnd((n, cout, h, w), 14), rnd((n, cout, h, w), 15)
+    w3r, w1r = w3.clone().requires_grad_(True), w1.clone().requires_grad_(True)
+    y3r, y1r = F.conv2d(x, w3r, None, padding=1), F.conv2d(x, w1r, None)
+    (y3r * g3).sum().backward()
+    (y1r * g1).sum().backward()
+    xp = torch.full((n, h, w, 4), 123.0)              # channels >= cin_w must not matter
+    xp[..., :cin_w] = x.permute(0, 2, 3, 1)
+    xg = xp.to(dev)
+    w3g, w1g = w3.permute(2, 3, 1, 0).contiguous().to(dev), w1.permute(2, 3, 1, 0).contiguous().to(dev)
+    assert ops._stem_case(4, cin_w, cout, 3)
+    y3, y1 = ops.stem_conv(xg, w3g, w1g)
+    close(y3.permute(0, 3, 1, 2), y3r)
+    close(y1.permute(0, 3, 1, 2), y1r)
+    y3b, none = ops.stem_conv(xg, w3g)
+    assert none is None and torch.equal(y3b, y3)
+    tol = 3e-4 * max(1.0, (n * h * w / 256.0) ** 0.5)
+    dw3 = ops.conv_wgrad(xg, g3.permute(0, 2, 3, 1).contiguous().to(dev), 3, 3, cin_w=cin_w)
+    assert tuple(dw3.shape) == (3, 3, cin_w, cout)
+    close(dw3.permute(3, 2, 0, 1), w3r.grad, tol=tol)
+    dw1 = ops.conv_wgrad(xg, g1.permute(0, 2, 3, 1).contiguous().to(dev), 1, 1, cin_w=cin_w)
+    close(dw1.permute(3, 2, 0, 1), w1r.grad, tol=tol)
+    again = ops.conv_wgrad(xg, g3.permute(0, 2, 3, 1).contiguous().to(dev), 3, 3, cin_w=cin_w)
+    assert torch.equal(again, dw3), "the stem weight gradient must be bitwise reproducible"
+
+
 @pytest.mark.parametrize("n,h,w,cin,cout", [(2, 4, 4, 64, 32), (1, 16, 16, 128, 64), (2, 8, 8, 32, 16)])
 def test_conv_transpose_k2s2(n, h, w, cin, cout):
     ops = _ops()

@@ -78,6 +78,18 @@ def main():
         n, h, w, cin, cout, dil = a[7:13]
         return f"{'F(4x4) wgrad':>14s} {n}x{h}x{w} {cin:4d}->{cout:4d} d{dil}", 2.0 * n * h * w * 9 * cin * cout, 4.0 * n * h * w * (cin + cout) * 2.25
 
+    def d_stem(a):       # x ldx w3 w1 y3 ldy3 y1 ldy1 n h w cin_w cout stream
+        n, h, w, cin_w, cout = a[8:13]
+        both = a[3] is not None
+        return (f"{'stem 3x3' + ('+1x1' if both else ''):>14s} {n}x{h}x{w} {cin_w:4d}->{cout:4d}", 2.0 * n * h * w * (10 if both else 9) * cin_w * cout,
+                4.0 * n * h * w * (4 + cout * (2 if both else 1)))
+
+    def d_stem_wgrad(a):  # x ldx dy ldy dw ws wsf n h w cin_w cout ksize stream
+        n, h, w, cin_w, cout, ks = a[7:13]
+        return f"{'stem wgrad':>14s} {n}x{h}x{w} {cin_w:4d}->{cout:4d} k{ks}", 2.0 * n * h * w * ks * ks * cin_w * cout, 4.0 * n * h * w * (4 + cout)
+
+    wrap("runet_stem_conv", d_stem)
+    wrap("runet_stem_wgrad", d_stem_wgrad)
     wrap("runet_conv_igemm", d_igemm)
     wrap("runet_conv_wgrad", d_wgrad)
     wrap("runet_wino_conv", d_wino)
