@@ -557,6 +557,194 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(WinoWgradArgs g) {
         }
 }
 
+// ---- the same weight gradient WITHOUT LDS and without barriers ("register-direct").
+// In v_mfma_f32_32x32x2_f32 lane (li, lh) supplies A[m = li][k = lh] and B[k = lh][n = li].  With m = input channel, n = output channel
+// and k = TILE, a lane that loads the x patch of (tile t + lh, cin li) and the 2x2 dy tile of (tile t + lh, cout li) can compute, in its
+// own registers, B^T d B and A dY A^T - which ARE its A and B operands for the Winograd positions of that k-step.  Nothing is exchanged
+// between lanes: no V / Z staging, no barrier.  A wave owns a 32 cin x 32 cout block of EIGHT positions (rows {0,1} or {2,3} of the 4x4
+// position grid: 8 accumulator tiles = 128 registers, 3 of the 4 patch rows, half the transform) and streams over its tile range; a
+// block is 8 waves = 2 x 2 (or 1 x 4) channel blocks x the two position halves, sharing one tile range (x / dy lines shared through L1).
+// Measured on the way here: a wave owning all 16 positions (256 accumulators, one wave per SIMD) runs VALU time PLUS matrix time - a
+// wave's own VALU work does not overlap its MFMAs (398 us = 250 MFMA + ~150 VALU at 64->64 @ 16x256x256, loads removed) - so two
+// waves per SIMD are needed for the transforms of one to hide under the MFMAs of the other.
+struct WinoWgradDirectArgs {
+    const float* x; int ldx;
+    const float* dy; int ldy;
+    float* slabs;                 // [splits][16][cin][cout]
+    int cin, cout, Nimg, H, W, TY, TX;
+    int wci;                      // channel blocks along cin (2: block = 64 cin x 64 cout, 1: block = 32 cin x 128 cout)
+    int ci_chunks, co_chunks, nchunks, nsplits;
+    long tiles, tiles_per_split;  // tiles_per_split even
+    long x_bytes, dy_bytes;       // extents for the bounds-checked buffer loads (< 2^31)
+    int abl;                      // timing ablations (wrong results): 1 = x loads dropped by the range check, 2 = dy loads, 3 = both
+};
+
+// PH: position half (rows 2*PH, 2*PH + 1 of the position grid).  CABL: compile-time timing ablations (4: no loads, 8: no MFMA).
+template <int PH, int CABL>
+__device__ __forceinline__ void wino_wgrad_direct_body(const WinoWgradDirectArgs& g, int bsplit, int bchunk, int sub, int lane) {
+    const int li = lane & 31, lh = lane >> 5;
+    const int wco = 4 / g.wci;
+    const int ca = (bchunk / g.co_chunks) * 32 * g.wci + (sub / wco) * 32 + li;      // this lane's input channel (A operand rows)
+    const int cb = (bchunk % g.co_chunks) * 32 * wco + (sub % wco) * 32 + li;        // this lane's output channel (B operand columns)
+    const bool ca_ok = ca < g.cin, cb_ok = cb < g.cout;
+    const long t_begin = (long)bsplit * g.tiles_per_split;
+    const long t_end = t_begin + g.tiles_per_split < g.tiles ? t_begin + g.tiles_per_split : g.tiles;
+    const int per = g.TY * g.TX;
+
+    // Addressing: bounds-checked buffer loads with 32-bit BYTE offsets (host guarantees both tensors < 2 GB).  Anything that must read as
+    // zero (halo outside the image, channels beyond cin / cout, tiles beyond the range) gets an offset >= 2^31, which the hardware range
+    // check turns into 0.0 - no select on loaded values.  Walking the tiles in (image, tile row, tile column) order the patch origin
+    // moves by a constant per step plus one image row at a tile-row wrap; the wrap into the next image needs nothing, (n*H + 2*ty) being
+    // the global pixel row.
+    const __amdgpu_buffer_rsrc_t rx_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.x), 0, (int)g.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.dy), 0, (int)g.dy_bytes, 0x00020000);
+    constexpr unsigned BIG = 0x80000000u;
+    const unsigned ldx4 = 4u * g.ldx, ldy4 = 4u * g.ldy, rowx4 = 4u * g.W * g.ldx, rowy4 = 4u * g.W * g.ldy;
+
+    const int t_end_i = (int)t_end;                     // tiles < 2^31 (host check)
+    int tg = (int)t_begin + lh;                         // this lane's tile: t_begin + lh, then += 2 per step
+    int tty, ttx;
+    unsigned offx, offy;                                // byte offsets of pixel (2ty, 2tx) (= patch element (1,1) = dy tile origin) + channel
+    {
+        const long tt = tg < g.tiles ? (long)tg : g.tiles - 1;
+        const int tn = (int)(tt / per);
+        const int rem = (int)(tt - (long)tn * per);
+        tty = rem / g.TX; ttx = rem - tty * g.TX;
+        offx = (unsigned)((((long)tn * g.H + 2 * tty) * g.W + 2 * ttx) * g.ldx + ca) * 4u;             // patch element (1, 1): always inside the image
+        offy = (unsigned)((((long)tn * g.H + 2 * tty) * g.W + 2 * ttx) * g.ldy + cb) * 4u;
+    }
+    // Software pipeline, one k-step (two tiles) per stage:  raw[3]: the loads of step s + 3 are issued during step s;  op[2]: step s + 1's
+    // operands are computed during step s.  Patch rows: half 0 needs rows 0,1,2, half 1 rows 1,2,3 -> raw_x[.][r] = patch row PH + r.
+    float raw_x[3][12], raw_y[3][4], op_v[2][8], op_z[2][8];
+    // All constant parts of an address (patch row a, patch column b, dy tile element) ride in the buffer load's SCALAR offset: the vector
+    // offset of every load of a stage is the patch origin itself or BIG.  fp32 MFMAs and VALU instructions compete for the same
+    // SIMD cycles (a step costs matrix time PLUS 4 cycles per VALU instruction, measured), so every v_add removed here is matrix time.
+    auto load = [&](float (&rx)[12], float (&ry)[4]) {
+        const bool tv = tg < t_end_i;
+        const unsigned ox = (tv && ca_ok && !(g.abl & 1)) ? offx : BIG, oy = (tv && cb_ok && !(g.abl & 2)) ? offy : BIG;
+        // Patch rows PH, PH+1, PH+2 (patch row 1 = pixel row 2ty): the first (PH = 0) or the last (PH = 1) of them may lie outside the
+        // image, as may patch columns 0 and 3.  Vector offsets never go below zero (the range check sees voffset alone): rows / columns in
+        // front of the origin subtract in the VALU and are only formed where they exist.
+        const bool edge_ok = PH == 0 ? tty > 0 : tty < g.TY - 1;
+        const bool left = ttx > 0, right = ttx < g.TX - 1;
+        const unsigned oe = edge_ok ? (PH == 0 ? ox - rowx4 : ox) : BIG;            // origin of the edge row (PH = 0: row 0, scalar part 0; PH = 1: row 3)
+        const unsigned ox_l = left ? ox - ldx4 : BIG, ox_r = right ? ox : BIG;
+        const unsigned oe_l = (left && edge_ok) ? oe - ldx4 : BIG, oe_r = right ? oe : BIG;
+        if constexpr (CABL & 4) {                       // timing ablation: no load instructions at all
+#pragma unroll
+            for (int i = 0; i < 12; ++i) rx[i] = __builtin_bit_cast(float, (i & 1 ? ox_l : oe_r) + (i & 2 ? oe_l : ox_r) + (unsigned)i);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ry[i] = __builtin_bit_cast(float, oy + i);
+        } else {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const bool e = (PH == 0 && a == 0) || (PH == 1 && a == 2);
+                // scalar part of patch row PH + a relative to its vector origin: PH = 0: rows 0,1,2 -> 0 (own origin), 0, rowx4; PH = 1: rows 1,2,3 -> 0, rowx4, 2 rowx4
+                const unsigned so = PH == 0 ? (a == 2 ? rowx4 : 0u) : (unsigned)a * rowx4;
+                rx[a * 4 + 0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx_, e ? oe_l : ox_l, so, 0));
+                rx[a * 4 + 1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx_, e ? oe : ox, so, 0));
+                rx[a * 4 + 2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx_, e ? oe : ox, so + ldx4, 0));
+                rx[a * 4 + 3] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx_, e ? oe_r : ox_r, so + 2 * ldx4, 0));
+            }
+            ry[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry_, oy, 0, 0));
+            ry[1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry_, oy, ldy4, 0));
+            ry[2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry_, oy, rowy4, 0));
+            ry[3] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry_, oy, rowy4 + ldy4, 0));
+        }
+        // advance by two tiles (TX >= 2: at most one wrap); branch-free, the loop body stays one basic block
+        tg += 2;
+        ttx += 2;
+        const bool wx = ttx >= g.TX;
+        ttx -= wx ? g.TX : 0;
+        tty += wx ? 1 : 0;
+        tty = tty >= g.TY ? 0 : tty;
+        offx += 4 * ldx4 + (wx ? rowx4 : 0u);
+        offy += 4 * ldy4 + (wx ? rowy4 : 0u);
+    };
+    // B^T d B rows {2PH, 2PH+1}: column pass over the three loaded rows, then the row pass;  A dY A^T rows likewise
+    auto transform = [&](const float (&r)[12], const float (&cy)[4], float (&v)[8], float (&z)[8]) {
+        float t0[4], t1[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            if constexpr (PH == 0) { t0[b] = r[b] - r[8 + b]; t1[b] = r[4 + b] + r[8 + b]; }            // d0 - d2, d1 + d2
+            else { t0[b] = r[4 + b] - r[b]; t1[b] = r[b] - r[8 + b]; }                                  // d2 - d1, d1 - d3
+        }
+        v[0] = t0[0] - t0[2]; v[1] = t0[1] + t0[2]; v[2] = t0[2] - t0[1]; v[3] = t0[1] - t0[3];
+        v[4] = t1[0] - t1[2]; v[5] = t1[1] + t1[2]; v[6] = t1[2] - t1[1]; v[7] = t1[1] - t1[3];
+        const float y00 = cy[0], y01 = cy[1], y10 = cy[2], y11 = cy[3];
+        float p0, q0, p1, q1;
+        if constexpr (PH == 0) { p0 = y00; q0 = y01; p1 = y00 + y10; q1 = y01 + y11; }
+        else { p0 = y00 - y10; q0 = y01 - y11; p1 = -y10; q1 = -y11; }
+        z[0] = p0; z[1] = p0 + q0; z[2] = p0 - q0; z[3] = -q0;
+        z[4] = p1; z[5] = p1 + q1; z[6] = p1 - q1; z[7] = -q1;
+    };
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+
+    // one stage: multiply step s (operands op[s & 1]) | transform step s + 1 | load step s + 3
+    auto stage = [&](int cur) {
+        transform(raw_x[(cur + 1) % 3], raw_y[(cur + 1) % 3], op_v[(cur + 1) & 1], op_z[(cur + 1) & 1]);
+        load(raw_x[cur % 3], raw_y[cur % 3]);
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            if constexpr (CABL & 8) acc[p][0] += op_v[cur & 1][p] * op_z[cur & 1][p];      // timing ablation: no MFMA
+            else acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(op_v[cur & 1][p], op_z[cur & 1][p], acc[p], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    load(raw_x[0], raw_y[0]);                           // past the end of the range: out-of-range offsets, zero values
+    load(raw_x[1], raw_y[1]);
+    load(raw_x[2], raw_y[2]);
+    transform(raw_x[0], raw_y[0], op_v[0], op_z[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    for (long tb = t_begin; tb < t_end; tb += 12) {     // six stages of two tiles (lcm of the two ring lengths); stages past t_end multiply zeros
+        stage(0);
+        stage(1);
+        stage(2);
+        stage(3);
+        stage(4);
+        stage(5);
+    }
+
+    float* slab = g.slabs + (long)bsplit * 16 * g.cin * g.cout;
+    const int ci_base = ca - li;
+    if (cb_ok) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = ci_base + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (ci < g.cin) slab[((long)(8 * PH + p) * g.cin + ci) * g.cout + cb] = acc[p][r];
+            }
+    }
+}
+
+template <int CABL>
+__global__ __launch_bounds__(512) void wino_wgrad_direct_kernel(WinoWgradDirectArgs g) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bsplit, bchunk;
+    {   // XCD-aware order (see wino_wgrad_kernel): the chunks of one tile range sit on one XCD
+        const int L = blockIdx.x, nch = g.nchunks, span = 8 * nch;
+        const int grp = L / span, r = L - grp * span;
+        bsplit = grp * 8 + (r & 7);
+        bchunk = r >> 3;
+        if (grp * 8 + 8 > g.nsplits) {
+            const int done = grp * 8, rem = g.nsplits - done;
+            bsplit = done + r % rem;
+            bchunk = r / rem;
+        }
+    }
+    // waves 2k, 2k+1 (position halves of channel block k) sit on different SIMDs; wave w and w + 4 share a SIMD: another channel block
+    if (wid & 1) wino_wgrad_direct_body<1, CABL>(g, bsplit, bchunk, wid >> 1, lane);
+    else wino_wgrad_direct_body<0, CABL>(g, bsplit, bchunk, wid >> 1, lane);
+}
+
 // dw[r][s][ci][co] = (G^T (sum_splits slab) G)[r][s];  block = 32 (ci,co) columns x 8 split-lanes
 __global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __restrict__ slabs, int nsplit, long kn, float* __restrict__ dw) {
     __shared__ float red[8][16][32];
@@ -596,9 +784,29 @@ __global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __r
     }
 }
 
-struct WinoWgradPlan { int ci_chunks, co_chunks, splits; long tiles, tps; };
-static WinoWgradPlan wino_wgrad_plan(int n_img, int h, int w, int cin, int cout) {
+struct WinoWgradPlan { int ci_chunks, co_chunks, splits, wci; long tiles, tps; };
+// register-direct form: needs 32-bit byte offsets (both tensors < 2 GB; the pixel strides are not known here, so the test is on the
+// channel counts and repeated with the real strides at launch) and at least two tile columns
+static bool wino_wgrad_direct(int n_img, int h, int w, long ldx, long ldy) {
+    static const bool lds_form = getenv("RUNET_WINO_WGRAD_LDS") && atoi(getenv("RUNET_WINO_WGRAD_LDS")) != 0;
+    const long px = (long)n_img * h * w;
+    return !lds_form && w >= 4 && px * ldx * 4 < (1L << 31) && px * ldy * 4 < (1L << 31) && px / 4 + 64 < (1L << 31);
+}
+static WinoWgradPlan wino_wgrad_plan(int n_img, int h, int w, int cin, int cout, bool direct) {
     WinoWgradPlan p{};
+    if (direct) {
+        // one block (four waves of 512 registers) per CU: ~256 blocks, or two rounds when the tile ranges stay long
+        p.wci = cin > 32 ? 2 : 1;
+        p.ci_chunks = cdiv(cin, 32 * p.wci); p.co_chunks = cdiv(cout, 32 * (4 / p.wci));
+        p.tiles = (long)n_img * (h / 2) * (w / 2);
+        long splits = cdiv(256, p.ci_chunks * p.co_chunks);
+        const long maxs = cdiv(p.tiles, 64);
+        if (splits > maxs) splits = maxs;
+        if (splits < 1) splits = 1;
+        p.tps = cdiv(cdiv(p.tiles, splits), 2) * 2L;
+        p.splits = cdiv(p.tiles, p.tps);
+        return p;
+    }
     p.ci_chunks = cdiv(cin, GCI); p.co_chunks = cdiv(cout, GCO);
     p.tiles = (long)n_img * (h / 2) * (w / 2);
     long splits = cdiv(640, p.ci_chunks * p.co_chunks);
@@ -657,8 +865,8 @@ extern "C" int runet_wino_conv(const float* x, int ldx, const float* U, const fl
 }
 
 extern "C" long runet_wino_wgrad_workspace_floats(int n_img, int h, int w, int cin, int cout) {
-    const WinoWgradPlan p = wino_wgrad_plan(n_img, h, w, cin, cout);
-    return (long)p.splits * 16 * cin * cout;
+    const WinoWgradPlan p = wino_wgrad_plan(n_img, h, w, cin, cout, false), q = wino_wgrad_plan(n_img, h, w, cin, cout, true);
+    return (long)(p.splits > q.splits ? p.splits : q.splits) * 16 * cin * cout;      // either form (chosen at launch from the pixel strides)
 }
 
 extern "C" int runet_wino_wgrad(const float* x, int ldx, const float* dy, int ldy, float* dw, float* workspace, long workspace_floats,
@@ -666,14 +874,28 @@ extern "C" int runet_wino_wgrad(const float* x, int ldx, const float* dy, int ld
     RUNET_REQUIRE(x && dy && dw && workspace, "null pointer");
     RUNET_REQUIRE(h % 2 == 0 && w % 2 == 0 && cin > 0 && cout > 0, "H and W must be even");
     RUNET_REQUIRE(ldx >= cin && ldy >= cout, "bad pixel strides");
-    const WinoWgradPlan p = wino_wgrad_plan(n_img, h, w, cin, cout);
+    const bool direct = wino_wgrad_direct(n_img, h, w, ldx, ldy);
+    const WinoWgradPlan p = wino_wgrad_plan(n_img, h, w, cin, cout, direct);
     RUNET_REQUIRE(workspace_floats >= (long)p.splits * 16 * cin * cout, "workspace too small (runet_wino_wgrad_workspace_floats)");
     hipStream_t st = (hipStream_t)stream;
     WinoWgradArgs a{};
     a.x = x; a.ldx = ldx; a.dy = dy; a.ldy = ldy; a.slabs = workspace; a.cin = cin; a.cout = cout; a.Nimg = n_img; a.H = h; a.W = w;
     a.TY = h / 2; a.TX = w / 2; a.co_chunks = p.co_chunks; a.tiles = p.tiles; a.tiles_per_split = p.tps;
     a.nchunks = p.ci_chunks * p.co_chunks; a.nsplits = p.splits;
-    hipLaunchKernelGGL(wino_wgrad_kernel, dim3(a.nchunks * p.splits), dim3(256), 0, st, a);
+    if (direct) {
+        WinoWgradDirectArgs d{};
+        d.x_bytes = (long)n_img * h * w * ldx * 4; d.dy_bytes = (long)n_img * h * w * ldy * 4;
+        static const int abl = getenv("RUNET_WINO_WGRAD_ABL") ? atoi(getenv("RUNET_WINO_WGRAD_ABL")) : 0;
+        d.abl = abl;
+        d.x = x; d.ldx = ldx; d.dy = dy; d.ldy = ldy; d.slabs = workspace; d.cin = cin; d.cout = cout; d.Nimg = n_img; d.H = h; d.W = w;
+        d.TY = h / 2; d.TX = w / 2; d.wci = p.wci; d.ci_chunks = p.ci_chunks; d.co_chunks = p.co_chunks; d.nchunks = p.ci_chunks * p.co_chunks;
+        d.nsplits = p.splits; d.tiles = p.tiles; d.tiles_per_split = p.tps;
+        if (abl & 4) hipLaunchKernelGGL(wino_wgrad_direct_kernel<4>, dim3(d.nchunks * p.splits), dim3(512), 0, st, d);
+        else if (abl & 8) hipLaunchKernelGGL(wino_wgrad_direct_kernel<8>, dim3(d.nchunks * p.splits), dim3(512), 0, st, d);
+        else hipLaunchKernelGGL(wino_wgrad_direct_kernel<0>, dim3(d.nchunks * p.splits), dim3(512), 0, st, d);
+    } else {
+        hipLaunchKernelGGL(wino_wgrad_kernel, dim3(a.nchunks * p.splits), dim3(256), 0, st, a);
+    }
     const long kn = (long)cin * cout;
     hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(cdiv(kn, 32)), dim3(256), 0, st, workspace, p.splits, kn, dw);
     RUNET_CHECK_LAUNCH();
