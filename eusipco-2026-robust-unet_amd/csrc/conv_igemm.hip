@@ -853,7 +853,33 @@ static bool use_tile_kernel(int kh, int kw, int dil, int transposed) {
     return (kh == 1 && kw == 1) || (kh == 3 && kw == 3 && dil == 1);
 }
 
+// 1x1 weight gradient = one TN GEMM over the pixels (dW[cin][cout] = x^T dy): rows per split so that ~512 blocks exist, 16-aligned
+static int wgrad1x1_rows_per_split(long P, int cin, int cout) {
+    // gemm.hip picks one-, two- or four-wave blocks by the output's size: aim at ~2048 waves on the chip
+    const int wm = cin > 64 ? 2 : 1, wn = cout > 64 ? 2 : 1;
+    const long tiles = (long)cdiv(cin, 64 * wm) * cdiv(cout, 64 * wn);
+    long splits = cdiv(2048, tiles * wm * wn);
+    const long maxs = P / 256 > 0 ? P / 256 : 1;
+    if (splits > maxs) splits = maxs;
+    return (int)((cdiv(P, splits) + 15) / 16 * 16);
+}
+// OPT-IN (RUNET_WGRAD1X1_GEMM=1): the 1x1 weight gradient as one TN GEMM over the pixels (gemm.hip).  Measured (tools/conv_launches.py,
+// 16 x 256^2 step, with RUNET_GEMM_TN_DIRECT=1): 1.1-1.5x faster than wgrad_tile_kernel<1,..> standalone on every shape except the
+// narrowest outputs at full resolution (64->32 @ 256^2: 170 vs 147 us), 1.66 vs 1.93 ms over the 16 launches - and no change of the step
+// time (36.17 vs 36.18 ms): weight gradients run on the side stream, off the critical path.  Default: the tile kernel.
+static bool wgrad1x1_direct(long P, int cin, int cout) {
+    static const bool on = getenv("RUNET_WGRAD1X1_GEMM") && atoi(getenv("RUNET_WGRAD1X1_GEMM")) != 0;
+    return on && P * 4 < (1L << 31) && !((long)cin * cout <= 8192 && P >= (1L << 19));
+}
+
 extern "C" long runet_conv_wgrad_workspace_floats(int n_img, int h, int w_, int cin_w, int cout, int kh, int kw) {
+    if (kh == 1 && kw == 1) {
+        const long P = (long)n_img * h * w_;
+        const long direct = (long)cdiv(P, wgrad1x1_rows_per_split(P, cin_w, cout)) * cin_w * cout;
+        TilePlan p = wgrad_tile_plan(n_img, h, w_, cin_w, cout, 1);
+        const long tile = p.splits > 1 ? (long)p.splits * cin_w * cout : 0;
+        return direct > tile ? direct : tile;
+    }
     if (kh == 3 && kw == 3 && cin_w <= 4) return (long)cdiv(h, 4) * n_img * 9 * cin_w * cout + 64L * 9 * cin_w * cout;   // stem kernel slabs
     if (kh == kw && (kh == 1 || kh == 3 || kh == 2)) {       // dilation unknown here: take the larger of the two plans
         TilePlan p = wgrad_tile_plan(n_img, h, w_, cin_w, cout, kh == 2 ? 1 : kh);
@@ -885,6 +911,18 @@ extern "C" int runet_conv_wgrad(const float* x, int ldx, const float* dy, int ld
         RUNET_REQUIRE(workspace && workspace_floats >= nblk * wsize, "workspace too small for the stem weight gradient");
         hipLaunchKernelGGL(stem_wgrad_kernel, dim3(cdiv(h, STEM_ROWS), n_img), dim3(256), 0, st, x, ldx, dy, ldy, workspace, h, w_, cin_w, cout);
         hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(wsize, 32 * 4)), dim3(256), 0, st, workspace, dw, wsize, nblk);
+        RUNET_CHECK_LAUNCH();
+    }
+    if (!transposed && kh == 1 && kw == 1 && cin_w == cin && wgrad1x1_direct((long)n_img * h * w_, cin, cout)) {
+        // register-direct TN GEMM (gemm.hip): both operands are read from HBM in MFMA operand order, no LDS, no VALU
+        const long P = (long)n_img * h * w_;
+        const int rps = wgrad1x1_rows_per_split(P, cin, cout);
+        const int splits = cdiv(P, rps);
+        const long wsize = (long)cin * cout;
+        RUNET_REQUIRE(splits == 1 || (workspace && workspace_floats >= splits * wsize), "workspace too small (runet_conv_wgrad_workspace_floats)");
+        const int rc = runet_gemm_tn_launch(x, ldx, 0, dy, ldy, 0, splits > 1 ? workspace : dw, 1, (int)P, cin, cout, rps, st);
+        if (rc) return rc;
+        if (splits > 1) hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(wsize, 32 * 4)), dim3(256), 0, st, workspace, dw, wsize, splits);
         RUNET_CHECK_LAUNCH();
     }
     if (use_tile_kernel(kh, kw, dil, transposed)) {

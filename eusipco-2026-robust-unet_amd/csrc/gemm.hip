@@ -286,6 +286,111 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmArgs g) {
     }
 }
 
+// ---- TN without LDS ("register-direct"): with the contraction over ROWS both operands are already in MFMA operand order in memory -
+// lane (li, lh) of v_mfma_f32_32x32x2_f32 supplies A[m = li][k = lh] and B[k = lh][n = li], i.e. 32 consecutive floats of row t + lh of
+// each matrix: one coalesced dword load per operand tile, straight into the register the MFMA reads.  No staging, no barrier, and no
+// VALU work at all: the per-lane part of an address is a constant vector offset, the row advance rides in the buffer load's scalar
+// offset.  (fp32 MFMAs and VALU instructions share SIMD cycles on gfx950 - see conv_winograd.hip - so "no VALU" is matrix time.)
+// Wave = 64 x 64 of C (2 x 2 MFMA tiles), block = 2 x 2 waves; a ring of D k2-steps of loads is in flight per wave.
+struct Yes { static constexpr bool value = true; };
+struct No { static constexpr bool value = false; };
+
+// TM x TN MFMA tiles per wave, WM x WN waves per block (block tile = 32 TM WM x 32 TN WN of C); D k2-steps of loads in flight.
+// Narrow outputs (the 1x1 weight gradients of 32- / 64-channel layers) use one- or two-wave blocks and more row splits instead of
+// multiplying zero columns.
+template <int TM, int TN, int WM, int WN, int D>
+__global__ __launch_bounds__(64 * WM * WN, TN >= 4 ? 2 : 1) void gemm_tn_direct_kernel(GemmArgs g) {
+    constexpr int BMT = 32 * TM * WM, BNT = 32 * TN * WN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wid / WN) * 32 * TM, wn0 = (wid % WN) * 32 * TN;
+    const int li = lane & 31, lh = lane >> 5;
+    const int n_tiles = (g.n + BNT - 1) / BNT;
+    const int k0 = (blockIdx.x / n_tiles) * BMT, n0 = (blockIdx.x % n_tiles) * BNT;
+    const int z = blockIdx.y;
+    const int t_begin = blockIdx.z * g.rps;
+    const int t_end = min(g.rows, t_begin + g.rps);
+    constexpr unsigned BIG = 0x80000000u;
+    // descriptors start at the split's first row: scalar offsets stay small, num_records = the split's bytes (< 2^31, host check)
+    const float* A = g.a + (long)z * g.sa + (long)t_begin * g.lda;
+    const float* B = g.b + (long)z * g.sb + (long)t_begin * g.ldb;
+    const int nrows = t_end - t_begin;
+    const __amdgpu_buffer_rsrc_t ra_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, nrows * g.lda * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(B), 0, nrows * g.ldb * 4, 0x00020000);
+    unsigned va[TM], vb[TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+        const int m = k0 + wm0 + a * 32 + li;
+        va[a] = m < g.k ? (unsigned)(lh * g.lda + m) * 4u : BIG;
+    }
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+        const int n = n0 + wn0 + b * 32 + li;
+        vb[b] = n < g.n ? (unsigned)(lh * g.ldb + n) * 4u : BIG;
+    }
+    const unsigned sa2 = 8u * g.lda, sb2 = 8u * g.ldb;          // bytes per k2-step (two rows)
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    float fa[D][TM], fb[D][TN];
+    unsigned soa = 0, sob = 0;                                  // scalar offsets of the next step to LOAD
+    int ls = 0;                                                 // ... and its index
+    // PRED: rows >= nrows (steps beyond the split, the odd last row) get the out-of-range vector offset and read as zero; the main loop's
+    // loads are all inside the split and carry no predicate (the scalar offset is NOT relied on for range checking)
+    auto load = [&](int d, auto pred) {
+        const bool ok = !decltype(pred)::value || 2 * ls + lh < nrows;
+#pragma unroll
+        for (int a = 0; a < TM; ++a) fa[d][a] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra_, ok ? va[a] : BIG, soa, 0));
+#pragma unroll
+        for (int b = 0; b < TN; ++b) fb[d][b] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb_, ok ? vb[b] : BIG, sob, 0));
+        soa += sa2; sob += sb2; ++ls;
+    };
+    auto mma = [&](int d) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[d][a], fb[d][b], acc[a][b], 0, 0, 0);
+    };
+    const int nsteps = (nrows + 1) >> 1;
+#pragma unroll
+    for (int d = 0; d < D; ++d) load(d, Yes{});
+    int s = 0;
+    for (; ls + D <= nsteps - 1; s += D) {                      // every load of this group targets a full step inside the split
+#pragma unroll
+        for (int d = 0; d < D; ++d) { mma(d); load(d, No{}); }
+    }
+    for (; s < nsteps; s += D) {                                // last groups: predicated loads; steps past the end multiply zeros
+#pragma unroll
+        for (int d = 0; d < D; ++d) { mma(d); load(d, Yes{}); }
+    }
+
+    float* C = g.c + ((long)blockIdx.z * gridDim.y + z) * g.k * g.n;
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+        const int col = n0 + wn0 + b * 32 + li;
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kk = k0 + wm0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (col < g.n && kk < g.k) C[(long)kk * g.n + col] = acc[a][b][r];
+            }
+    }
+}
+
+template <int TM, int TN, int WM, int WN>
+void launch_tn_direct(const GemmArgs& g, int batch, hipStream_t st) {
+    constexpr int D = (TM + TN) >= 6 ? 6 : ((TM + TN) >= 4 ? 8 : 12);      // 24-36 dword loads in flight per wave (wide tile: <= 256 registers)
+    hipLaunchKernelGGL((gemm_tn_direct_kernel<TM, TN, WM, WN, D>), dim3(cdiv(g.k, 32 * TM * WM) * cdiv(g.n, 32 * TN * WN), batch, cdiv(g.rows, g.rps)),
+                       dim3(64 * WM * WN), 0, st, g);
+}
+
 }  // namespace
 
 int runet_gemm_nn_launch(const float* a, int lda, long sa, const float* b, long sb, float* c, int ldc, long sc, int batch, int rows, int k, int n,
@@ -301,6 +406,37 @@ int runet_gemm_tn_launch(const float* a, int lda, long sa, const float* b, int l
                          hipStream_t st) {
     GemmArgs g{};
     g.a = a; g.lda = lda; g.sa = sa; g.b = b; g.ldb = ldb; g.sb = sb; g.c = c; g.rows = rows; g.k = k; g.n = n; g.rps = rps;
+    // The register-direct form is OPT-IN (RUNET_GEMM_TN_DIRECT=1).  Standalone it is 8-10 % faster than the LDS-ring kernel on the eleven
+    // F(4x4) weight-gradient GEMMs of a 16 x 256^2 step (2.53 vs 2.75 ms, 96-117 vs 87-105 TFLOP/s executed) - but these GEMMs run on the
+    // weight-gradient side stream, and there the direct form makes the STEP slower (36.55 vs 36.17 ms, two runs each): at 16 FLOP per
+    // loaded byte it pulls 4+ TB/s through L2 beside the main chain's streaming kernels, the LDS form (32 FLOP/B) half of that.  A wider
+    // wave tile (64 x 128, RUNET_GEMM_TN_WIDE=1) was slower even standalone (272 vs 208 us).
+    static const bool lds_form = !(getenv("RUNET_GEMM_TN_DIRECT") && atoi(getenv("RUNET_GEMM_TN_DIRECT")) != 0);
+    static const bool wide = getenv("RUNET_GEMM_TN_WIDE") && atoi(getenv("RUNET_GEMM_TN_WIDE")) != 0;
+    const long split_rows = rows < rps ? rows : rps;
+    // register-direct form: 32-bit byte offsets inside one split, D steps of slack past the end of the offset range
+    if (!lds_form && (split_rows + 64) * lda * 4 < (1L << 31) && (split_rows + 64) * ldb * 4 < (1L << 31)) {
+        // per dimension: 1 tile (<= 32), 2 tiles in one wave (<= 64), 2 waves of 2 tiles (> 64)
+        const int cm = k <= 32 ? 0 : (k <= 64 ? 1 : 2), cn = n <= 32 ? 0 : (n <= 64 ? 1 : 2);
+        switch (cm * 3 + cn) {
+        case 0: launch_tn_direct<1, 1, 1, 1>(g, batch, st); break;
+        case 1: launch_tn_direct<1, 2, 1, 1>(g, batch, st); break;
+        case 2: launch_tn_direct<1, 2, 1, 2>(g, batch, st); break;
+        case 3: launch_tn_direct<2, 1, 1, 1>(g, batch, st); break;
+        case 4: launch_tn_direct<2, 2, 1, 1>(g, batch, st); break;
+        case 5: launch_tn_direct<2, 2, 1, 2>(g, batch, st); break;
+        case 6: launch_tn_direct<2, 1, 2, 1>(g, batch, st); break;
+        case 7: launch_tn_direct<2, 2, 2, 1>(g, batch, st); break;
+        default:
+            // wide outputs: 64 x 128 per wave (128 accumulators) raises the FLOPs per loaded byte from 16 to 21 - these GEMMs draw
+            // 4+ TB/s through L2 with the 64 x 64 wave tile.  RUNET_GEMM_TN_WIDE=0 keeps the square tile (measurement knob).
+            if (wide && n >= 256) launch_tn_direct<2, 4, 2, 2>(g, batch, st);
+            else if (wide && n > 64 && n <= 128) launch_tn_direct<2, 4, 2, 1>(g, batch, st);
+            else launch_tn_direct<2, 2, 2, 2>(g, batch, st);
+            break;
+        }
+        return 0;
+    }
     hipLaunchKernelGGL(gemm_tn_kernel, dim3(cdiv(k, 128) * cdiv(n, 128), batch, cdiv(rows, rps)), dim3(256), 3 * TN_STAGE * sizeof(float), st, g);
     return 0;
 }

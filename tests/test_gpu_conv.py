@@ -252,3 +252,17 @@ def test_data_gradient_on_pre_transposed_weights_equals_the_default_path(k, dil)
     finally:
         ops.USE_TRANSPOSED_DGRAD = False
     assert torch.equal(got, ref) and torch.equal(gott, reft)
+
+
+def test_opt_in_direct_gemm_paths_in_a_child_process():
+    """RUNET_GEMM_TN_DIRECT / RUNET_WGRAD1X1_GEMM (register-direct TN GEMM for the F(4x4) and 1x1 weight gradients; off by default because
+    they slow the step down from the side stream, see csrc/gemm.hip) are read once per process: the F(4x4) and generic convolution tests
+    run again in a child with both set."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, RUNET_GEMM_TN_DIRECT="1", RUNET_WGRAD1X1_GEMM="1")
+    here = os.path.abspath(__file__)
+    r = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-x", "-k", "winograd_f4 or fwd_dgrad_wgrad", "-p", "no:cacheprovider"],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=os.path.dirname(os.path.dirname(here)))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

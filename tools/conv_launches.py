@@ -88,6 +88,16 @@ def main():
         n, h, w, cin_w, cout, ks = a[7:13]
         return f"{'stem wgrad':>14s} {n}x{h}x{w} {cin_w:4d}->{cout:4d} k{ks}", 2.0 * n * h * w * ks * ks * cin_w * cout, 4.0 * n * h * w * (4 + cout)
 
+    def d_gemm_tn(a):    # a lda sa b ldb sb c batch rows k n rps stream
+        batch, rows, k, n = a[7:11]
+        return f"{'gemm TN (F4 wg)':>14s} {batch}x[{rows}x{k}]^T[{rows}x{n}]", 4.0 * 2.0 * batch * rows * k * n, 4.0 * batch * rows * (k + n)
+
+    def d_gemm_nn(a):    # a lda sa b sb c ldc sc batch rows k n stream
+        batch, rows, k, n = a[8:12]
+        return f"{'gemm NN (F4)':>14s} {batch}x[{rows}x{k}][{k}x{n}]", 4.0 * 2.0 * batch * rows * k * n, 4.0 * batch * (rows * (k + n) + k * n)
+
+    wrap("runet_gemm_tn_batched", d_gemm_tn)
+    wrap("runet_gemm_batched", d_gemm_nn)
     wrap("runet_stem_conv", d_stem)
     wrap("runet_stem_wgrad", d_stem_wgrad)
     wrap("runet_conv_igemm", d_igemm)
