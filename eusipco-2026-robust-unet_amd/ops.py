@@ -422,7 +422,7 @@ def _conv_wgrad(x, dy, kh, kw, cin_w=None, dil=1, out=None, v=None):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     if USE_WINOGRAD and kh == 3 and dil == 1 and cin_w == cin and h % 2 == 0 and w % 2 == 0 and cin >= 16:
-        name = "wino_wgrad_kernel(+reduce)"
+        name = "wino_wgrad_direct_kernel(+reduce)"
         nws = lib.runet_wino_wgrad_workspace_floats(n, h, w, cin, cout)
         ws = workspace(nws, x.device)
         check(lib.runet_wino_wgrad(x.data_ptr(), ld(x), dy.data_ptr(), ld(dy), out.data_ptr(), ws.data_ptr(), ws.numel(), n, h, w, cin, cout, stream()))
