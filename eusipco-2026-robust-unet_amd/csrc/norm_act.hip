@@ -15,6 +15,7 @@
 namespace {
 
 constexpr int TPB = 256;
+constexpr int STATS_GROUPS = 16;      // chan_stats_partial: threads per channel in the row combine when there are few channels
 
 struct Welf { float n, mean, m2; };
 
@@ -48,14 +49,15 @@ __global__ __launch_bounds__(TPB) void chan_stats_partial(const float* __restric
     for (int v = 0; v < VEC; ++v) { K[v] = 0.f; s1[v] = 0.f; s2[v] = 0.f; mx[v] = -FLT_MAX; mn[v] = FLT_MAX; imx[v] = 0; imn[v] = 0; }
     if (active) {
         const float* base = x + ((long)n * HW) * ld + col * VEC;
-        for (int p = p0 + row; p < p1; p += rows) {
-            float v[VEC];
+        auto fetch = [&](int p, float (&v)[VEC]) {
             if constexpr (VEC == 4) {
                 const f32x4 t = *reinterpret_cast<const f32x4*>(base + (long)p * ld);
                 v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
             } else {
                 v[0] = base[(long)p * ld];
             }
+        };
+        auto take = [&](int p, const float (&v)[VEC]) {
             if (cnt == 0) {
 #pragma unroll
                 for (int q = 0; q < VEC; ++q) K[q] = v[q];
@@ -71,6 +73,18 @@ __global__ __launch_bounds__(TPB) void chan_stats_partial(const float* __restric
                 }
             }
             ++cnt;
+        };
+        int p = p0 + row;
+        // four loads in flight per thread (a read-only stream needs them: 3.9 TB/s with one); the pixels are still taken in order
+        for (; p + 3 * rows < p1; p += 4 * rows) {
+            float v0[VEC], v1[VEC], v2[VEC], v3[VEC];
+            fetch(p, v0); fetch(p + rows, v1); fetch(p + 2 * rows, v2); fetch(p + 3 * rows, v3);
+            take(p, v0); take(p + rows, v1); take(p + 2 * rows, v2); take(p + 3 * rows, v3);
+        }
+        for (; p < p1; p += rows) {
+            float v[VEC];
+            fetch(p, v);
+            take(p, v);
         }
     }
     // per-thread (n, mean, M2) -> LDS [row][C][3] (+ minmax [row][C][4])
@@ -92,11 +106,9 @@ __global__ __launch_bounds__(TPB) void chan_stats_partial(const float* __restric
         }
     }
     __syncthreads();
-    for (int c = tid; c < C; c += TPB) {
-        double n_ = 0, mean = 0, m2 = 0;
-        float bmx = -FLT_MAX, bmn = FLT_MAX;
-        int bimx = 0, bimn = 0;
-        for (int r = 0; r < rows; ++r) {
+    // rows r0, r0 + rstep, ... of channel c -> (n, mean, M2[, max, min, first indices])
+    auto combine_rows = [&](int c, int r0, int r1, double& n_, double& mean, double& m2, float& bmx, float& bmn, int& bimx, int& bimn) {
+        for (int r = r0; r < r1; ++r) {
             const float* d = w3 + (r * C + c) * 3;
             chan_combine(n_, mean, m2, d[0], d[1], d[2]);
             if constexpr (MINMAX) {
@@ -108,6 +120,48 @@ __global__ __launch_bounds__(TPB) void chan_stats_partial(const float* __restric
                 }
             }
         }
+    };
+    if (C * STATS_GROUPS <= TPB && rows >= 2 * STATS_GROUPS) {
+        // few channels (the attention gates' single-channel maps: rows = 256): one thread combining all the rows in double precision is
+        // a 256-step serial chain per workgroup (12 us); STATS_GROUPS threads per channel take contiguous row ranges, then one combines them
+        float* g3 = sm + rows * C * (MINMAX ? 7 : 3);            // [group][C][7]
+        const int c = tid % C, grp = tid / C;
+        if (grp < STATS_GROUPS) {
+            const int per = (rows + STATS_GROUPS - 1) / STATS_GROUPS;
+            double n_ = 0, mean = 0, m2 = 0;
+            float bmx = -FLT_MAX, bmn = FLT_MAX;
+            int bimx = 0, bimn = 0;
+            combine_rows(c, grp * per, min(rows, grp * per + per), n_, mean, m2, bmx, bmn, bimx, bimn);
+            float* o = g3 + (grp * C + c) * 7;
+            o[0] = (float)n_; o[1] = (float)mean; o[2] = (float)m2; o[3] = bmx; o[4] = bmn; o[5] = __int_as_float(bimx); o[6] = __int_as_float(bimn);
+        }
+        __syncthreads();
+        if (tid < C) {
+            double n_ = 0, mean = 0, m2 = 0;
+            float bmx = -FLT_MAX, bmn = FLT_MAX;
+            int bimx = 0, bimn = 0;
+            for (int q = 0; q < STATS_GROUPS; ++q) {
+                const float* d = g3 + (q * C + tid) * 7;
+                chan_combine(n_, mean, m2, d[0], d[1], d[2]);
+                if constexpr (MINMAX) {
+                    if (d[0] > 0.f) {
+                        const int i1 = __float_as_int(d[5]), i2 = __float_as_int(d[6]);
+                        if (d[3] > bmx || (d[3] == bmx && i1 < bimx)) { bmx = d[3]; bimx = i1; }
+                        if (d[4] < bmn || (d[4] == bmn && i2 < bimn)) { bmn = d[4]; bimn = i2; }
+                    }
+                }
+            }
+            float* o = part + (((long)n * nchunks + chunk) * C + tid) * (MINMAX ? 7 : 3);
+            o[0] = (float)n_; o[1] = (float)mean; o[2] = (float)m2;
+            if constexpr (MINMAX) { o[3] = bmx; o[4] = bmn; o[5] = __int_as_float(bimx); o[6] = __int_as_float(bimn); }
+        }
+        return;
+    }
+    for (int c = tid; c < C; c += TPB) {
+        double n_ = 0, mean = 0, m2 = 0;
+        float bmx = -FLT_MAX, bmn = FLT_MAX;
+        int bimx = 0, bimn = 0;
+        combine_rows(c, 0, rows, n_, mean, m2, bmx, bmn, bimx, bimn);
         float* o = part + (((long)n * nchunks + chunk) * C + c) * (MINMAX ? 7 : 3);
         o[0] = (float)n_; o[1] = (float)mean; o[2] = (float)m2;
         if constexpr (MINMAX) { o[3] = bmx; o[4] = bmn; o[5] = __int_as_float(bimx); o[6] = __int_as_float(bimn); }
@@ -261,8 +315,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_partial(const float* __rest
     }
     if (row < rows) {
         const long ib = (long)n * HW;
-        for (int p = p0 + row; p < p1; p += rows) {
-            float g[VEC], xv[VEC], av[VEC];
+        auto fetch = [&](int p, float (&g)[VEC], float (&xv)[VEC], float (&av)[VEC]) {
             if constexpr (VEC == 4) {
                 const f32x4 t = *reinterpret_cast<const f32x4*>(dy + (ib + p) * lddy + col * 4);
                 const f32x4 u = *reinterpret_cast<const f32x4*>(x + (ib + p) * ldx + col * 4);
@@ -276,6 +329,8 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_partial(const float* __rest
                 g[0] = dy[(ib + p) * lddy + col]; xv[0] = x[(ib + p) * ldx + col];
                 if (act) av[0] = act[(ib + p) * ldact + col];
             }
+        };
+        auto take = [&](const float (&g)[VEC], const float (&xv)[VEC], const float (&av)[VEC]) {
 #pragma unroll
             for (int q = 0; q < VEC; ++q) {
                 float gg = g[q];
@@ -284,6 +339,17 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_partial(const float* __rest
                 sg[q] += gg;
                 sgx[q] += gg * (xv[q] - mu[q]) * is[q];
             }
+        };
+        int p = p0 + row;
+        for (; p + rows < p1; p += 2 * rows) {           // two pixels' loads in flight per thread; same summation order
+            float g0[VEC], x0[VEC], a0[VEC], g1[VEC], x1[VEC], a1[VEC];
+            fetch(p, g0, x0, a0); fetch(p + rows, g1, x1, a1);
+            take(g0, x0, a0); take(g1, x1, a1);
+        }
+        for (; p < p1; p += rows) {
+            float g0[VEC], x0[VEC], a0[VEC];
+            fetch(p, g0, x0, a0);
+            take(g0, x0, a0);
         }
 #pragma unroll
         for (int q = 0; q < VEC; ++q) {
@@ -420,8 +486,11 @@ __global__ __launch_bounds__(TPB) void chan_sum_final(const float* __restrict__ 
 inline int final_cw(int c, long nparts = 0) { const int w = nparts >= 256 ? 4 : 32; return c >= w ? w : c; }
 
 inline int pick_chunks(int N, int HW, int C, int rows) {
-    // ~32 vector loads per thread; at least one pass of `rows` pixels per chunk
+    // ~32 vector loads per thread; at least one pass of `rows` pixels per chunk; and at least ~768 workgroups on the chip: the
+    // single-channel maps of the attention gates (16 x 256 x 256 x 1: two chunks per image = 32 workgroups) took 61 us for 4 MB
     long per_img = ((long)HW * C + 32767) / 32768;
+    const long want = (768 + N - 1) / N;
+    if (per_img < want) per_img = want;
     if (per_img < 1) per_img = 1;
     if (per_img > 1024) per_img = 1024;
     long maxc = (HW + rows - 1) / rows;
@@ -470,7 +539,7 @@ extern "C" int runet_chan_stats(const float* x, int ld, int n_img, int hw, int c
     const int cvec = c / vec, rows = TPB / cvec;
     const int chunks = pick_chunks(n_img, hw, c, rows);
     const int ppc = (hw + chunks - 1) / chunks;
-    const size_t lds = (size_t)rows * c * (want_minmax ? 7 : 3) * sizeof(float);
+    const size_t lds = ((size_t)rows * c * (want_minmax ? 7 : 3) + (c * STATS_GROUPS <= TPB ? STATS_GROUPS * c * 7 : 0)) * sizeof(float);
     RUNET_REQUIRE(lds <= 64 * 1024, "LDS budget");
     dim3 grid(chunks, n_img);
 #define LAUNCH_STATS(V, MM) hipLaunchKernelGGL((chan_stats_partial<V, MM>), grid, dim3(TPB), lds, st, x, ld, hw, c, ppc, workspace)
