@@ -51,8 +51,8 @@ _scratch = {}
 
 
 def scratch(nfloats, device):
-    """Per-device reduction workspace (partials); grows monotonically."""
-    return ops.grow(_scratch, device.index, nfloats, device, 1 << 21)
+    """Reduction workspace (partials) per device AND stream (forward branches / weight gradients run beside the main chain); grows monotonically."""
+    return ops.grow(_scratch, (device.index, torch.cuda.current_stream().cuda_stream), nfloats, device, 1 << 21)
 
 
 def _ws(n, hw, c, device):
@@ -197,13 +197,18 @@ def rb_forward(x, p: RBParams, training, mask=None, save=True, stats_hook=None):
     st = ops.stream()
     sm = Small(x.device)
     kv1, kv2 = ({}, {}) if save else (None, None)      # F(4x4) layers: the transformed inputs are kept for the weight gradients
-    t1 = None
+    t1, br = None, None
     if p.ws is not None:
         if ops._stem_case(x.shape[3], p.cin_w, c, 3) and p.ws.shape[2] == p.cin_w:
             t1, r = ops.stem_conv(x, p.w1, p.ws)       # RGB stem: conv1 and the shortcut convolution in one launch
+            ss, hs, mean_s, invstd_s, _ = bn_coeff(r, p.bns, training, sm, stats_hook=stats_hook)
         else:
-            r = ops.conv_fwd(x, p.ws)
-        ss, hs, mean_s, invstd_s, _ = bn_coeff(r, p.bns, training, sm, stats_hook=stats_hook)
+            # the shortcut branch (1x1 convolution + its BatchNorm statistics) runs beside conv1 .. the attention maps, joins at rb_out
+            sm.f(4)                                    # the arena's buffer is allocated on the main stream
+            br = ops.side_branch(stats_hook is None)
+            with br:
+                r = ops.conv_fwd(x, p.ws)
+                ss, hs, mean_s, invstd_s, _ = bn_coeff(r, p.bns, training, sm, stats_hook=stats_hook)
     else:
         r, ss, hs, mean_s, invstd_s = x, None, None, None, None
     if t1 is None:
@@ -227,6 +232,8 @@ def rb_forward(x, p: RBParams, training, mask=None, save=True, stats_hook=None):
     sa = torch.empty(P, device=x.device, dtype=torch.float32)
     check(lib.runet_sa_conv7(smap.data_ptr(), p.wsa.data_ptr(), sa.data_ptr(), n, h, w, st))
     out = ops.empty_nhwc(n, h, w, c, x)
+    if br is not None:
+        br.join(r)
     check(lib.runet_rb_out(t2.data_ptr(), ops.ld(t2), A.data_ptr(), B.data_ptr(), sa.data_ptr(), r.data_ptr(), ops.ld(r),
                            ss.data_ptr() if ss is not None else None, hs.data_ptr() if hs is not None else None, out.data_ptr(),
                            ops.ld(out), P, hw, c, st))
@@ -455,16 +462,29 @@ class UpGateParams:
             wup, bup, wg, bg, bng, wx, bx, bnx, wpsi, bpsi, bnp)
 
 
-def gate_forward(up, skip, p: UpGateParams, training, att_out, sm, stats_hook=None):
-    """AttentionGate(g=up, x=skip) -> writes skip*psi into att_out; returns ctx pieces."""
+def gate_x_branch(skip, p: UpGateParams, training, sm, stats_hook=None):
+    """W_x(skip) + its BatchNorm statistics on the side stream: independent of the gate signal, so upgate_forward starts it in front of
+    the transposed convolution.  -> (branch handle, x1, (scale, shift, mean, invstd))"""
+    sm.f(4)
+    br = ops.side_branch(stats_hook is None)
+    with br:
+        x1 = ops.conv_fwd(skip, p.wx, p.bx)
+        sx, hx, mean_x, invstd_x, _ = bn_coeff(x1, p.bnx, training, sm, stats_hook=stats_hook)
+    return br, x1, (sx, hx, mean_x, invstd_x)
+
+
+def gate_forward(up, skip, p: UpGateParams, training, att_out, sm, stats_hook=None, xb=None):
+    """AttentionGate(g=up, x=skip) -> writes skip*psi into att_out; returns ctx pieces.  xb: gate_x_branch() started earlier."""
     n, h, w, c = skip.shape
     f = p.wg.shape[3]
     P = n * h * w
     st = ops.stream()
+    if xb is None:
+        xb = gate_x_branch(skip, p, training, sm, stats_hook)
     g1 = ops.conv_fwd(up, p.wg, p.bg)
-    x1 = ops.conv_fwd(skip, p.wx, p.bx)
     sg, hg, mean_g, invstd_g, _ = bn_coeff(g1, p.bng, training, sm, stats_hook=stats_hook)
-    sx, hx, mean_x, invstd_x, _ = bn_coeff(x1, p.bnx, training, sm, stats_hook=stats_hook)
+    br, x1, (sx, hx, mean_x, invstd_x) = xb
+    br.join(x1)
     s = torch.empty((n, h, w, 1), device=skip.device, dtype=torch.float32)
     check(lib.runet_ag_psi(g1.data_ptr(), ops.ld(g1), x1.data_ptr(), ops.ld(x1), sg.data_ptr(), hg.data_ptr(), sx.data_ptr(), hx.data_ptr(),
                            p.wpsi.data_ptr(), p.bpsi.data_ptr(), s.data_ptr(), P, f, st))
@@ -518,8 +538,9 @@ def upgate_forward(y, skip, p: UpGateParams, training, save=True, stats_hook=Non
     sm = Small(skip.device)
     cat = ops.empty_nhwc(n, h, w, 2 * c, skip)
     up = cat[..., c:]
+    xb = gate_x_branch(skip, p, training, sm, stats_hook)
     ops.convt_fwd(y, p.wup, p.bup, out=up)
-    gc = gate_forward(up, skip, p, training, cat[..., :c], sm, stats_hook)
+    gc = gate_forward(up, skip, p, training, cat[..., :c], sm, stats_hook, xb=xb)
     if not save:
         return cat, None
     gc.update(y=y, skip=skip, cat=cat, p=p)

@@ -381,6 +381,47 @@ def side_stream():
     return _side.get("active")
 
 
+# ---- forward-pass branches on the same side stream: the pass is one dependent chain, but a ResidualBlock's shortcut (1x1 convolution +
+# BatchNorm statistics) does not depend on its main branch, nor the attention gate's W_x(skip) on the transposed convolution that produces
+# the gate signal.  The side stream is idle in the forward pass; the branch joins where its result is consumed.
+FWD_BRANCHES = os.environ.get("RUNET_FWD_BRANCHES", "1") != "0"
+
+
+class side_branch:
+    """br = ops.side_branch(); with br: ...independent work...; later br.join(tensors allocated inside the branch)."""
+
+    def __init__(self, enabled=True):
+        self.s = None
+        if (enabled and FWD_BRANCHES and USE_WGRAD_STREAM and torch.cuda.is_available() and _side.get("active") is None
+                and not torch.cuda.is_current_stream_capturing()):
+            dev = torch.cuda.current_device()
+            if ("s", dev) not in _side:
+                _side[("s", dev)] = torch.cuda.Stream(device=dev)
+            self.s = _side[("s", dev)]
+
+    def __enter__(self):
+        if self.s is not None:
+            self.s.wait_stream(torch.cuda.current_stream())
+            self.ctx = torch.cuda.stream(self.s)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.s is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+    def join(self, *tensors):
+        """The current stream waits for the branch; tensors the branch allocated are marked as used by the current stream."""
+        if self.s is not None:
+            cur = torch.cuda.current_stream()
+            cur.wait_stream(self.s)
+            for t in tensors:
+                if t is not None:
+                    t.record_stream(cur)
+            self.s = None
+
+
 def _on_side(fn, tensors):
     s = _side.get("active")
     if s is None:
