@@ -466,6 +466,8 @@ def _net_forward(net: RobustUNet, x, save, want_logit=False):
     hook = net.sync_bn_hook if tr else None
     n = x.shape[0]
     dev = x.device
+    if save:
+        ops.prefetch_derived()          # stale Winograd filters / packed weights: refilled on the side stream while the stem runs
     x0 = B.to_nhwc_pad(x, (net.n_channels + 3) // 4 * 4)
     rbs = net._rbs()
     masks = {k: (rb.dropout.draw(n, rb.out_channels, dev) if tr else None) for k, rb in rbs.items()}

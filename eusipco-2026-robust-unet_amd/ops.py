@@ -80,16 +80,64 @@ def bump_weight_epoch():
 
 
 def _cached(w, kind, make):
+    """make(out) -> the derived tensor (out = None: allocate; else refill that tensor in place)"""
     base = w._base if w._base is not None else w
     key = (w.data_ptr(), kind)
     tag = (base._version, WEIGHT_EPOCH, tuple(w.shape))
     hit = _derived.get(key)
     # the weak reference pins the entry to THIS parameter tensor: another model's weight allocated later at the same address misses
     if hit is not None and hit[0] == tag and hit[2]() is base:
+        ev = hit[4]
+        if ev is not None:                         # refilled by prefetch_derived on the side stream: order this stream behind it, once
+            sid = torch.cuda.current_stream().cuda_stream
+            if sid not in ev[1]:
+                torch.cuda.current_stream().wait_event(ev[0])
+                ev[1].add(sid)
         return hit[1]
-    val = make()
-    _derived[key] = (tag, val, weakref.ref(base))
+    val = make(None)
+    _derived[key] = [tag, val, weakref.ref(base), make, None]
     return val
+
+
+PREFETCH_DERIVED = os.environ.get("RUNET_PREFETCH_DERIVED", "1") != "0"
+
+
+def prefetch_derived():
+    """Called at the start of a training forward pass: refill, on the idle side stream, every derived weight (Winograd-domain filters,
+    packed bf16 / fp16 weights) that the optimizer step has made stale - in the order the previous step first used them, forward kinds
+    first.  The main stream waits for ONE event (recorded behind the forward kinds) the first time it touches a refilled entry, and for a
+    second one behind the data-gradient kinds; no per-entry events (those cost more than the launches they moved: an earlier version with
+    one event per entry was 0.7 % slower).  Refilled IN PLACE: every reader of the old values was enqueued before the optimizer launch,
+    which the side stream waits for.  -> number of entries refilled"""
+    if not (PREFETCH_DERIVED and FWD_BRANCHES and USE_WGRAD_STREAM and _derived) or torch.cuda.is_current_stream_capturing():
+        return 0
+    todo = []
+    for key, ent in list(_derived.items()):
+        base = ent[2]()
+        if base is None:
+            del _derived[key]
+        elif (ent[0][0], ent[0][1]) != (base._version, WEIGHT_EPOCH):
+            todo.append((key[1].endswith("d") or key[1].endswith("t") or key[1] == "T", ent, base))
+    if not todo:
+        return 0
+    br = side_branch()
+    if br.s is None:
+        return 0
+    side_id = br.s.cuda_stream
+    with br:
+        for want_bwd in (False, True):             # forward kinds first: they are needed within the first half millisecond
+            group = [(e, b) for is_bwd, e, b in todo if is_bwd == want_bwd]
+            if not group:
+                continue
+            for ent, base in group:
+                ent[3](ent[1])
+                ent[0] = (base._version, WEIGHT_EPOCH, ent[0][2])
+            ev = [torch.cuda.Event(), {side_id}]
+            ev[0].record(br.s)
+            for ent, _ in group:
+                ent[4] = ev
+    br.s = None                                    # no join: consumers wait on the events
+    return len(todo)
 
 
 # Measured: reading the data gradients' weights from a cached per-tap transposed copy (modes *_DGRAD_T, n-contiguous staging) instead of the
@@ -102,8 +150,8 @@ def transposed_weights(w_hwio):
     """[taps][cin][cout] -> [taps][cout][cin] (cached per optimizer step) for the *_DGRAD_T modes of runet_conv_igemm."""
     kh, kw, cin, cout = w_hwio.shape
 
-    def make():
-        wt = torch.empty((kh, kw, cout, cin), device=w_hwio.device, dtype=torch.float32)
+    def make(out):
+        wt = out if out is not None else torch.empty((kh, kw, cout, cin), device=w_hwio.device, dtype=torch.float32)
         check(lib.runet_transpose_taps(w_hwio.data_ptr(), wt.data_ptr(), kh * kw, cin, cout, stream()))
         return wt
     return _cached(w_hwio, "T", make)
@@ -123,12 +171,16 @@ def bf16_weights(w_hwio, transpose=False):
     """HWIO fp32 weight [kh, kw, cin, cout] -> packed bf16 [taps][K/8][N][8] (forward: K = cin; transpose: K = cout, data gradients)."""
     kh, kw, cin, cout = w_hwio.shape
 
-    def make():
+    prec = _PRECISION                                   # bound now: a refill ahead of use runs outside the precision context
+    tdtype, tname = _LOWP[prec]
+    pack_elems, pack = getattr(lib, f"runet_{tname}_pack_elems"), getattr(lib, f"runet_{tname}_pack_weights")
+
+    def make(out):
         k, n = (cout, cin) if transpose else (cin, cout)
-        buf = torch.empty(_lp("runet_{}_pack_elems")(kh * kw, k, n), device=w_hwio.device, dtype=_LOWP[_PRECISION][0])
-        check(_lp("runet_{}_pack_weights")(w_hwio.data_ptr(), buf.data_ptr(), kh * kw, cin, cout, int(transpose), stream()))
+        buf = out if out is not None else torch.empty(pack_elems(kh * kw, k, n), device=w_hwio.device, dtype=tdtype)
+        check(pack(w_hwio.data_ptr(), buf.data_ptr(), kh * kw, cin, cout, int(transpose), stream()))
         return buf
-    return _cached(w_hwio, _PRECISION + ("t" if transpose else ""), make)
+    return _cached(w_hwio, prec + ("t" if transpose else ""), make)
 
 
 def _igemm_bf16(mode, x, w_hwio, bias, out, n, h, wd, cin, cout, kh, kw, dil, accumulate, transpose):
@@ -298,8 +350,8 @@ def wino_weights(w_hwio, dgrad=False):
     _, _, cin, cout = w_hwio.shape
     k, n = (cout, cin) if dgrad else (cin, cout)
 
-    def make():
-        U = torch.empty((16, k, n), device=w_hwio.device, dtype=torch.float32)
+    def make(out):
+        U = out if out is not None else torch.empty((16, k, n), device=w_hwio.device, dtype=torch.float32)
         check(lib.runet_wino_weights(w_hwio.data_ptr(), U.data_ptr(), cin, cout, int(dgrad), stream()))
         return U
     return _cached(w_hwio, "wino2d" if dgrad else "wino2", make)
@@ -746,8 +798,8 @@ def wino4_weights(w_hwio, dgrad=False):
     _, _, cin, cout = w_hwio.shape
     k, n = (cout, cin) if dgrad else (cin, cout)
 
-    def make():
-        U = torch.empty((36, k, n), device=w_hwio.device, dtype=torch.float32)
+    def make(out):
+        U = out if out is not None else torch.empty((36, k, n), device=w_hwio.device, dtype=torch.float32)
         check(lib.runet_wino4_weights(w_hwio.data_ptr(), U.data_ptr(), cin, cout, int(dgrad), stream()))
         return U
     return _cached(w_hwio, "wino4d" if dgrad else "wino4", make)

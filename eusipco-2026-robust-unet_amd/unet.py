@@ -132,6 +132,8 @@ def unet_forward(net: UNet, x, save=True):
     sm = B.Small(dev)
     n = x.shape[0]
     C = {}
+    if save:
+        ops.prefetch_derived()
     cur = B.to_nhwc_pad(x, (net.n_channels + 3) // 4 * 4)
     cats = {}
     for lvl, ch in enumerate(CH, 1):
