@@ -466,6 +466,7 @@ def _net_forward(net: RobustUNet, x, save, want_logit=False):
     hook = net.sync_bn_hook if tr else None
     n = x.shape[0]
     dev = x.device
+    ops.branches_pay(n, x.shape[2], x.shape[3])
     if save:
         ops.prefetch_derived()          # stale Winograd filters / packed weights: refilled on the side stream while the stem runs
     x0 = B.to_nhwc_pad(x, (net.n_channels + 3) // 4 * 4)

@@ -109,7 +109,7 @@ def prefetch_derived():
     second one behind the data-gradient kinds; no per-entry events (those cost more than the launches they moved: an earlier version with
     one event per entry was 0.7 % slower).  Refilled IN PLACE: every reader of the old values was enqueued before the optimizer launch,
     which the side stream waits for.  -> number of entries refilled"""
-    if not (PREFETCH_DERIVED and FWD_BRANCHES and USE_WGRAD_STREAM and _derived) or torch.cuda.is_current_stream_capturing():
+    if not (PREFETCH_DERIVED and FWD_BRANCHES and _branch_now and USE_WGRAD_STREAM and _derived) or torch.cuda.is_current_stream_capturing():
         return 0
     todo = []
     for key, ent in list(_derived.items()):
@@ -437,6 +437,17 @@ def side_stream():
 # BatchNorm statistics) does not depend on its main branch, nor the attention gate's W_x(skip) on the transposed convolution that produces
 # the gate signal.  The side stream is idle in the forward pass; the branch joins where its result is consumed.
 FWD_BRANCHES = os.environ.get("RUNET_FWD_BRANCHES", "1") != "0"
+# Branching costs host time (stream switches, event waits: +1.5-2.5 ms per step measured at 2 x 256^2 and 2 x 64^2, where the step is bound
+# by the host issuing launches) and buys GPU time: the models switch it on per forward pass from the input size (branches_pay).
+BRANCH_MIN_PIXELS = int(os.environ.get("RUNET_BRANCH_MIN_PIXELS", str(1 << 18)))
+_branch_now = True
+
+
+def branches_pay(n, h, w):
+    """Called by a model at the start of its forward pass: forward branches / derived-weight prefetch only for GPU-bound step sizes."""
+    global _branch_now
+    _branch_now = n * h * w >= BRANCH_MIN_PIXELS
+    return _branch_now
 
 
 class side_branch:
@@ -444,7 +455,7 @@ class side_branch:
 
     def __init__(self, enabled=True):
         self.s = None
-        if (enabled and FWD_BRANCHES and USE_WGRAD_STREAM and torch.cuda.is_available() and _side.get("active") is None
+        if (enabled and FWD_BRANCHES and _branch_now and USE_WGRAD_STREAM and torch.cuda.is_available() and _side.get("active") is None
                 and not torch.cuda.is_current_stream_capturing()):
             dev = torch.cuda.current_device()
             if ("s", dev) not in _side:

@@ -132,6 +132,7 @@ def unet_forward(net: UNet, x, save=True):
     sm = B.Small(dev)
     n = x.shape[0]
     C = {}
+    ops.branches_pay(n, x.shape[2], x.shape[3])
     if save:
         ops.prefetch_derived()
     cur = B.to_nhwc_pad(x, (net.n_channels + 3) // 4 * 4)

@@ -13,8 +13,9 @@ DEV = "cuda:0"
 def _run(pkg, oracle, flags, precision, steps=5):
     ops = importlib.import_module("eusipco-2026-robust-unet_amd.ops")
     trainer = importlib.import_module("eusipco-2026-robust-unet_amd.trainer")
-    old = ops.PREFETCH_DERIVED, ops.FWD_BRANCHES
+    old = ops.PREFETCH_DERIVED, ops.FWD_BRANCHES, ops.BRANCH_MIN_PIXELS
     ops.PREFETCH_DERIVED, ops.FWD_BRANCHES = flags
+    ops.BRANCH_MIN_PIXELS = 0                         # the models switch branching off for small (host-bound) steps: force it for 2 x 64^2
     ops._derived.clear()
     try:
         m = pkg.RobustUNet(3, 1, 64)
@@ -30,7 +31,7 @@ def _run(pkg, oracle, flags, precision, steps=5):
         torch.cuda.synchronize()
         return m, losses, refilled
     finally:
-        ops.PREFETCH_DERIVED, ops.FWD_BRANCHES = old
+        ops.PREFETCH_DERIVED, ops.FWD_BRANCHES, ops.BRANCH_MIN_PIXELS = old
 
 
 @pytest.mark.parametrize("precision", ["f32", "bf16", "fp16"])
