@@ -52,7 +52,7 @@ _scratch = {}
 
 def scratch(nfloats, device):
     """Reduction workspace (partials) per device AND stream (forward branches / weight gradients run beside the main chain); grows monotonically."""
-    return ops.grow(_scratch, (device.index, torch.cuda.current_stream().cuda_stream), nfloats, device, 1 << 21)
+    return ops.grow(_scratch, (device.index, ops.stream()), nfloats, device, 1 << 21)
 
 
 def _ws(n, hw, c, device):

@@ -33,8 +33,15 @@ def grow(pool, key, nfloats, device, floor):
     return buf
 
 
+_STREAM_OVERRIDE = None      # raw handle of the weight-gradient stream while a launch is being redirected to it (_on_side)
+
+
 def stream():
-    return torch.cuda.current_stream().cuda_stream
+    """Raw handle of the stream the next kernel goes to.  torch.cuda.current_stream() costs ~8 us (device-index resolution, availability check); the
+    ops ask for the stream ~500 times per step, which is 4 ms of a host-bound small step - the raw getter costs 0.3 us."""
+    if _STREAM_OVERRIDE is not None:
+        return _STREAM_OVERRIDE
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 # ---- operand precision of the matrix-core kernels.  "f32": the reference's arithmetic (fp32 MFMA, Winograd forms included).
@@ -89,7 +96,7 @@ def _cached(w, kind, make):
     if hit is not None and hit[0] == tag and hit[2]() is base:
         ev = hit[4]
         if ev is not None:                         # refilled by prefetch_derived on the side stream: order this stream behind it, once
-            sid = torch.cuda.current_stream().cuda_stream
+            sid = stream()
             if sid not in ev[1]:
                 torch.cuda.current_stream().wait_event(ev[0])
                 ev[1].add(sid)
@@ -217,7 +224,7 @@ def empty_nhwc(n, h, w, c, like):
 
 
 def workspace(nfloats, device):
-    key = (device.index, "wgrad", torch.cuda.current_stream().cuda_stream)      # one scratch per stream (weight gradients may run on a side stream)
+    key = (device.index, "wgrad", stream())      # one scratch per stream (weight gradients may run on a side stream)
     return grow(_ws, key, nfloats, device, 1 << 22)
 
 
@@ -420,6 +427,8 @@ class wgrad_side_stream:
             if ("s", dev) not in _side:
                 _side[("s", dev)] = torch.cuda.Stream(device=dev)
             _side["active"] = _side[("s", dev)]
+            _side["active_raw"] = _side["active"].cuda_stream
+            _side["torch_switch"] = torch.cuda.is_current_stream_capturing()      # captured fork / join (GRAPH_SIDE): through torch's stream objects
         return self
 
     def __exit__(self, *exc):
@@ -486,12 +495,26 @@ class side_branch:
 
 
 def _on_side(fn, tensors):
+    """Run fn's launches on the weight-gradient stream, behind everything enqueued on the current stream so far.  The kernels take their
+    stream from ops.stream(), so the redirection is an override of that handle plus one event record / wait in C - torch's current stream
+    is not switched (wait_stream + the stream context manager cost ~25 us of host time per call, 50 calls per step).  Only the live
+    conv profile (HIP events recorded on torch's current stream) still goes through the torch-level switch."""
+    global _STREAM_OVERRIDE
     s = _side.get("active")
     if s is None:
         return fn()
-    s.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(s):
-        r = fn()
+    if _PROFILE is not None or _side.get("torch_switch"):
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            r = fn()
+    else:
+        raw = _side["active_raw"]
+        check(lib.runet_stream_wait(raw, stream()))
+        _STREAM_OVERRIDE = raw
+        try:
+            r = fn()
+        finally:
+            _STREAM_OVERRIDE = None
     for t in tensors:
         if t is not None:
             t.record_stream(s)
@@ -796,7 +819,7 @@ _ws4 = {}
 
 
 def _workspace4(nfloats, device):
-    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    key = (device.index, stream())
     return grow(_ws4, key, nfloats, device, 1)
 
 

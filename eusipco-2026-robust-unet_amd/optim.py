@@ -108,11 +108,11 @@ class FusedAdam(torch.optim.Optimizer):
                     hyper, step_dev, _ = self._device_hyper(gi, group, plist[0].device, step - 1)
                 check(lib.runet_adam_multi_dev(d_tab.data_ptr(), len(plist), d_chunks.data_ptr(), n_chunks, hyper.data_ptr(), step_dev.data_ptr(),
                                                self.skip_flag.data_ptr() if self.skip_flag is not None else None,
-                                               torch.cuda.current_stream().cuda_stream))
+                                               ops.stream()))
                 continue
             b1, b2 = group["betas"]
             check(lib.runet_adam_multi(d_tab.data_ptr(), len(plist), d_chunks.data_ptr(), n_chunks, float(group["lr"]), float(b1), float(b2),
                                        float(group["eps"]), float(group["weight_decay"]), int(step), float(self.grad_scale),
                                        self.skip_flag.data_ptr() if self.skip_flag is not None else None,
-                                       torch.cuda.current_stream().cuda_stream))
+                                       ops.stream()))
         return loss

@@ -182,6 +182,10 @@ int runet_adam_multi_dev(const long long* table, int n_tensors, const int* chunk
                          const int* skip_flag, void* stream);
 /* loss scaling: flag2[0] = 1 iff buf[0:n] holds an Inf / NaN (reset by this call), flag2[1] += flag2[0] (running count of skipped steps) */
 int runet_nonfinite_flag(const float* buf, long n, int* flag2, void* stream);
+/* stream `waiter` waits for everything enqueued on stream `waited` so far (event record + stream wait on a pooled event): host-side helper
+ * of the weight-gradient side stream (the all-reduce / backward overlap of Main_Final.py:581's loss.backward()). */
+int runet_stream_wait(void* waiter, void* waited);
+
 
 /* ---- ModelEvaluator.calculate_metrics counts (Main_Final.py:519-547): counts[n] = {tp, pred>thr, target!=0, agree} ---- */
 int runet_seg_counts(const float* pred, const float* target, long long* counts, int n_img, long per_img, float threshold, void* stream);
