@@ -7,6 +7,7 @@ channel slice of a wider concat buffer).  All launches go to torch's current HIP
 from __future__ import annotations
 
 import os
+import threading
 import weakref
 
 import torch
@@ -33,14 +34,16 @@ def grow(pool, key, nfloats, device, floor):
     return buf
 
 
-_STREAM_OVERRIDE = None      # raw handle of the weight-gradient stream while a launch is being redirected to it (_on_side)
+_tls = threading.local()     # .override: raw handle of the weight-gradient stream while THIS thread redirects a launch to it (_on_side);
+#                              per thread: the autograd engine runs backward passes on its own threads
 
 
 def stream():
     """Raw handle of the stream the next kernel goes to.  torch.cuda.current_stream() costs ~8 us (device-index resolution, availability check); the
     ops ask for the stream ~500 times per step, which is 4 ms of a host-bound small step - the raw getter costs 0.3 us."""
-    if _STREAM_OVERRIDE is not None:
-        return _STREAM_OVERRIDE
+    o = getattr(_tls, "override", None)
+    if o is not None:
+        return o
     return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
@@ -499,7 +502,6 @@ def _on_side(fn, tensors):
     stream from ops.stream(), so the redirection is an override of that handle plus one event record / wait in C - torch's current stream
     is not switched (wait_stream + the stream context manager cost ~25 us of host time per call, 50 calls per step).  Only the live
     conv profile (HIP events recorded on torch's current stream) still goes through the torch-level switch."""
-    global _STREAM_OVERRIDE
     s = _side.get("active")
     if s is None:
         return fn()
@@ -510,11 +512,11 @@ def _on_side(fn, tensors):
     else:
         raw = _side["active_raw"]
         check(lib.runet_stream_wait(raw, stream()))
-        _STREAM_OVERRIDE = raw
+        _tls.override = raw
         try:
             r = fn()
         finally:
-            _STREAM_OVERRIDE = None
+            _tls.override = None
     for t in tensors:
         if t is not None:
             t.record_stream(s)
