@@ -44,7 +44,12 @@ struct IGemmArgs {
     int zbatch;
 };
 
-template <int BM, int BN, int WM, int WN, bool KCONTIG>
+// SIMPLE: a plain 1x1 convolution (one tap, source pixel == GEMM row, K a multiple of 16 and fully backed by x and w): every address
+// is a pointer set up once and advanced by a constant per k-step, nothing is predicated (rows / columns beyond the problem are clamped
+// to valid addresses: their products land in output rows / columns that are never stored).  The general loader recomputes tap geometry,
+// bounds and 64-bit addresses every k-step: ~220 VALU instructions (20 of them quarter-rate integer multiplies) per 32 MFMAs, and fp32
+// MFMAs share SIMD cycles with VALU work (conv_winograd.hip) - the 1x1 forward / data-gradient launches ran at 52-69 TFLOP/s with it.
+template <int BM, int BN, int WM, int WN, bool KCONTIG, bool SIMPLE = false>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(IGemmArgs g) {
     constexpr int LDA = 20;
     constexpr int LDB = BN + 4;
@@ -107,7 +112,45 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IGemmArgs g) {
     f32x4 rb[BREGS];
     int ld_tr = 0, ld_ts = 0, ld_kc = 0, ld_tap = 0;   // counters of the NEXT tile to load
 
+    // SIMPLE: running pointers of this thread's A rows and B float4s
+    const float* ap[AROWS];
+    const float* bp[BREGS];
+    long bstep = 0;
+    if constexpr (SIMPLE) {
+#pragma unroll
+        for (int i = 0; i < AROWS; ++i)                  // a_ok false: pixel 0 (a_img = a_h = a_w = 0 from pp = 0 above)
+            ap[i] = xb + (a_img[i] + (long)a_h[i] * g.Win + a_w[i]) * g.ldx + akq * 4;
+        if constexpr (!KCONTIG) {
+            constexpr int NQ = BN / 4;
+            constexpr int KSTEP = 256 / NQ;
+#pragma unroll
+            for (int i = 0; i < BREGS; ++i) {
+                const int nq = tid % NQ;
+                int kr = tid / NQ + KSTEP * i, n = n0 + nq * 4;
+                kr = kr < 16 ? kr : 15;
+                n = n < g.Ncols ? n : g.Ncols - 4;
+                bp[i] = wbase + (long)kr * g.w_sk + n;
+            }
+            bstep = 16L * g.w_sk;
+        } else {
+#pragma unroll
+            for (int i = 0; i < BREGS; ++i) {
+                int n = n0 + (tid >> 2) + 64 * i;
+                n = n < g.Ncols ? n : g.Ncols - 1;
+                bp[i] = wbase + (long)n * g.w_sn + akq * 4;
+            }
+            bstep = 16;
+        }
+    }
+
     auto load_tile = [&]() {
+        if constexpr (SIMPLE) {
+#pragma unroll
+            for (int i = 0; i < AROWS; ++i) { ra[i] = *reinterpret_cast<const f32x4*>(ap[i]); ap[i] += 16; }
+#pragma unroll
+            for (int i = 0; i < BREGS; ++i) { rb[i] = *reinterpret_cast<const f32x4*>(bp[i]); bp[i] += bstep; }
+            return;
+        }
         int dh = ld_tr * g.tdh, dw = ld_ts * g.tdw;
         int wtap = ld_tap;
         if (g.zmode4) { dh = ph4 - ld_tr; dw = pw4 - ld_ts; wtap = (1 - ph4 + 2 * ld_tr) * 4 + (1 - pw4 + 2 * ld_ts); }
@@ -699,7 +742,11 @@ void launch_igemm(const IGemmArgs& a, int gz, hipStream_t st) {
     const long P = (long)a.Nimg * a.H * a.W;
     dim3 grid(cdiv(P, BM), cdiv(a.Ncols, BN), gz);
     const size_t lds = 2 * (BM * 20 + 16 * (BN + 4)) * sizeof(float);
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, KC>), grid, dim3(256), lds, st, a);
+    static const bool no_simple = getenv("RUNET_IGEMM_GENERAL") && atoi(getenv("RUNET_IGEMM_GENERAL")) != 0;      // measurement knob
+    const bool simple = !no_simple && a.KH == 1 && a.KW == 1 && a.a_scale == 1 && a.a_div <= 1 && !a.zmode4 && a.z_taps == 0 && a.bh == 0 &&
+                        a.bw == 0 && a.Hin == a.H && a.Win == a.W && a.K % 16 == 0 && a.Kx >= a.K && a.Kvalid >= a.K && a.Ncols >= 4 && P > 0;
+    if (simple) hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, KC, true>), grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, KC, false>), grid, dim3(256), lds, st, a);
 }
 
 enum IGemmVariant { V_128x32 = 0, V_256x64 = 1, V_128x64 = 2, V_128x128 = 3, V_64x64 = 4 };
