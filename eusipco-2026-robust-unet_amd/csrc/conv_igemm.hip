@@ -44,8 +44,9 @@ struct IGemmArgs {
     int zbatch;
 };
 
-// SIMPLE: a plain 1x1 convolution (one tap, source pixel == GEMM row, K a multiple of 16 and fully backed by x and w): every address
-// is a pointer set up once and advanced by a constant per k-step, nothing is predicated (rows / columns beyond the problem are clamped
+// SIMPLE: every tap of every row lies inside the source image (plain 1x1 convolutions, the k2-s2 transposed convolution both ways), K a
+// multiple of 16 and fully backed by x and w: every address is a per-thread pointer set up once plus a wave-uniform offset per k-step,
+// nothing is predicated (rows / columns beyond the problem are clamped
 // to valid addresses: their products land in output rows / columns that are never stored).  The general loader recomputes tap geometry,
 // bounds and 64-bit addresses every k-step: ~220 VALU instructions (20 of them quarter-rate integer multiplies) per 32 MFMAs, and fp32
 // MFMAs share SIMD cycles with VALU work (conv_winograd.hip) - the 1x1 forward / data-gradient launches ran at 52-69 TFLOP/s with it.
@@ -145,10 +146,18 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IGemmArgs g) {
 
     auto load_tile = [&]() {
         if constexpr (SIMPLE) {
+            // wave-uniform offsets of the tile (tap shift of the source pixel, channel chunk, weight tap): scalar arithmetic only
+            const long offa = ((long)(ld_tr * g.tdh) * g.Win + ld_ts * g.tdw) * g.ldx + ld_kc * 16;
+            const long offb = (long)ld_tap * g.w_tap_stride + (long)ld_kc * bstep;
 #pragma unroll
-            for (int i = 0; i < AROWS; ++i) { ra[i] = *reinterpret_cast<const f32x4*>(ap[i]); ap[i] += 16; }
+            for (int i = 0; i < AROWS; ++i) ra[i] = *reinterpret_cast<const f32x4*>(ap[i] + offa);
 #pragma unroll
-            for (int i = 0; i < BREGS; ++i) { rb[i] = *reinterpret_cast<const f32x4*>(bp[i]); bp[i] += bstep; }
+            for (int i = 0; i < BREGS; ++i) rb[i] = *reinterpret_cast<const f32x4*>(bp[i] + offb);
+            ++ld_tap;
+            if (++ld_ts == g.KW) {
+                ld_ts = 0;
+                if (++ld_tr == g.KH) { ld_tr = 0; ld_tap = 0; ++ld_kc; }
+            }
             return;
         }
         int dh = ld_tr * g.tdh, dw = ld_ts * g.tdw;
@@ -743,8 +752,12 @@ void launch_igemm(const IGemmArgs& a, int gz, hipStream_t st) {
     dim3 grid(cdiv(P, BM), cdiv(a.Ncols, BN), gz);
     const size_t lds = 2 * (BM * 20 + 16 * (BN + 4)) * sizeof(float);
     static const bool no_simple = getenv("RUNET_IGEMM_GENERAL") && atoi(getenv("RUNET_IGEMM_GENERAL")) != 0;      // measurement knob
-    const bool simple = !no_simple && a.KH == 1 && a.KW == 1 && a.a_scale == 1 && a.a_div <= 1 && !a.zmode4 && a.z_taps == 0 && a.bh == 0 &&
-                        a.bw == 0 && a.Hin == a.H && a.Win == a.W && a.K % 16 == 0 && a.Kx >= a.K && a.Kvalid >= a.K && a.Ncols >= 4 && P > 0;
+    // every tap of every row inside the source image, no coordinate division: the plain 1x1 convolution (also the four 1x1 GEMMs of the
+    // k2-s2 transposed forward, z_taps > 0) and the k2-s2 transposed convolution's data gradient (source pixel (2h + r, 2w + s))
+    const bool plain1 = a.KH == 1 && a.KW == 1 && a.a_scale == 1 && a.Hin == a.H && a.Win == a.W;
+    const bool up2 = a.KH == 2 && a.KW == 2 && a.z_taps == 0 && a.a_scale == 2 && a.tdh == 1 && a.tdw == 1 && a.Hin == 2 * a.H && a.Win == 2 * a.W;
+    const bool simple = !no_simple && (plain1 || up2) && a.a_div <= 1 && !a.zmode4 && a.bh == 0 && a.bw == 0 && a.K % 16 == 0 && a.Kx >= a.K &&
+                        a.Kvalid >= a.K && a.Ncols >= 4 && P > 0;
     if (simple) hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, KC, true>), grid, dim3(256), lds, st, a);
     else hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, KC, false>), grid, dim3(256), lds, st, a);
 }
