@@ -1167,12 +1167,13 @@ extern "C" const char* runet_gemm_batched_kernel_name(int batch, int rows, int k
     static const bool old_path = getenv("RUNET_GEMM_OLD") != nullptr;
     const long b128 = (long)cdiv(rows, 128) * cdiv(n, 128) * batch;
     const double per_cu = b128 / 256.0, bal = per_cu / (double)((b128 + 255) / 256);
-    if (!old_path && bal < 0.8 && n % 64 == 0) return "igemm_kernel<128, 64, 64, 32, false>";
-    if (!old_path && n >= 96) return "gemm_nn_kernel<16>";
-    if (n % 128 == 0 && b128 >= 256) return "igemm_kernel<128, 128, 64, 64, false>";
-    if (n > 32 && (long)cdiv(rows, 128) * cdiv(n, 64) * batch >= 256) return "igemm_kernel<128, 64, 64, 32, false>";
-    if (n > 32) return "igemm_kernel<64, 64, 32, 32, false>";
-    return "igemm_kernel<128, 32, 32, 32, false>";
+    const bool fast = k % 16 == 0 && k >= 16 && n >= 4;       // the FAST / SIMPLE instantiations (last template argument)
+    if (!old_path && bal < 0.8 && n % 64 == 0) return fast ? "igemm_kernel<128, 64, 64, 32, false, true>" : "igemm_kernel<128, 64, 64, 32, false, false>";
+    if (!old_path && n >= 96) return fast ? "gemm_nn_kernel<16, true>" : "gemm_nn_kernel<16, false>";
+    if (n % 128 == 0 && b128 >= 256) return fast ? "igemm_kernel<128, 128, 64, 64, false, true>" : "igemm_kernel<128, 128, 64, 64, false, false>";
+    if (n > 32 && (long)cdiv(rows, 128) * cdiv(n, 64) * batch >= 256) return fast ? "igemm_kernel<128, 64, 64, 32, false, true>" : "igemm_kernel<128, 64, 64, 32, false, false>";
+    if (n > 32) return fast ? "igemm_kernel<64, 64, 32, 32, false, true>" : "igemm_kernel<64, 64, 32, 32, false, false>";
+    return fast ? "igemm_kernel<128, 32, 32, 32, false, true>" : "igemm_kernel<128, 32, 32, 32, false, false>";
 }
 
 extern "C" int runet_gemm_batched(const float* a, int lda, long stride_a, const float* b, long stride_b, float* c, int ldc, long stride_c,

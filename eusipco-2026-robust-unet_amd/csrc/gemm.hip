@@ -34,7 +34,11 @@ struct NNCfg {
     static constexpr int NKH = KB / 8;                // 8-deep fragment groups per step
 };
 
-template <int KB>
+// FAST (k a multiple of KB - every layer of the network): loads are unconditional and nothing is zero-filled.  Rows beyond `rows` and
+// columns beyond `n` are clamped to valid addresses at set-up (their products land in output rows / columns that are never stored), the
+// tiles prefetched past the end re-read the last k-tile.  The general form spends ~55 VALU instructions per 32 MFMAs on predicates,
+// address selects and zero selects; fp32 MFMAs share SIMD cycles with VALU work (conv_winograd.hip).
+template <int KB, bool FAST = false>
 __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(GemmArgs g) {
     using C = NNCfg<KB>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -62,7 +66,19 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(GemmArgs g) {
     // s+3 are issued in step s and stored at the end of step s+1 - two whole steps (~5000 cycles) to arrive.  With one set (issued and
     // stored in the same step) every step ended in a vmcnt wait for loads that take longer than a step under load: 58 % MFMA-busy.
     struct Raw { f32x4 ra[C::AV], rb[C::BV]; bool oka[C::AV], okb[C::BV]; };
+    long boff[C::BV];                                  // FAST: B float4 of k-row (tid >> 5) + 8v at k-tile 0
+#pragma unroll
+    for (int v = 0; v < C::BV; ++v) boff[v] = (long)((tid >> 5) + 8 * v) * g.ldb + (bn_ok ? bcol : (g.n >= 4 ? g.n - 4 : 0));
     auto load_tile = [&](int kofs, Raw& R) {
+        if constexpr (FAST) {
+            const int kc = kofs < g.k ? kofs : g.k - KB;                   // wave-uniform
+            const long kb = (long)kc * g.ldb;
+#pragma unroll
+            for (int v = 0; v < C::AV; ++v) R.ra[v] = *reinterpret_cast<const f32x4*>(A + aoff[v] + kc);
+#pragma unroll
+            for (int v = 0; v < C::BV; ++v) R.rb[v] = *reinterpret_cast<const f32x4*>(B + boff[v] + kb);
+            return;
+        }
 #pragma unroll
         for (int v = 0; v < C::AV; ++v) {
             R.oka[v] = aok[v] && kofs + akq * 4 < g.k;
@@ -80,9 +96,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(GemmArgs g) {
         float* Bs = As + C::A;
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int v = 0; v < C::AV; ++v) *reinterpret_cast<f32x4*>(As + (arow + ARSTEP * v) * C::LDA + akq * 4) = R.oka[v] ? R.ra[v] : zero;
+        for (int v = 0; v < C::AV; ++v)
+            *reinterpret_cast<f32x4*>(As + (arow + ARSTEP * v) * C::LDA + akq * 4) = (FAST || R.oka[v]) ? R.ra[v] : zero;
 #pragma unroll
-        for (int v = 0; v < C::BV; ++v) *reinterpret_cast<f32x4*>(Bs + ((tid >> 5) + 8 * v) * C::LDB + bnq * 4) = R.okb[v] ? R.rb[v] : zero;
+        for (int v = 0; v < C::BV; ++v)
+            *reinterpret_cast<f32x4*>(Bs + ((tid >> 5) + 8 * v) * C::LDB + bnq * 4) = (FAST || R.okb[v]) ? R.rb[v] : zero;
     };
 
     f32x16 acc[2][2];
@@ -171,6 +189,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(GemmArgs g) {
 constexpr int TN_LD = 128 + 4;
 constexpr int TN_STAGE = 2 * BK * TN_LD;
 
+// FAST (every split a whole number of 16-row tiles): unconditional loads, nothing zero-filled - columns beyond k / n are clamped to valid
+// addresses (their products are never stored), the tiles prefetched past the end re-read the split's last tile into a stage nobody reads.
+template <bool FAST>
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -190,6 +211,16 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmArgs g) {
     const int acol = ak_ok ? k0 + q4 : 0, bcol = bn_ok ? n0 + q4 : 0;
     struct Raw { f32x4 ra[2], rb[2]; bool okt[2]; };      // two sets: loads issued two steps ahead of their LDS store (see gemm_nn_kernel)
     auto load_tile = [&](int t0, Raw& R) {
+        if constexpr (FAST) {
+            const int tc = t0 < t_end ? t0 : t_end - BK;                    // wave-uniform
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                const long tr = tc + (tid >> 5) + 8 * v;
+                R.ra[v] = *reinterpret_cast<const f32x4*>(A + tr * g.lda + acol);
+                R.rb[v] = *reinterpret_cast<const f32x4*>(B + tr * g.ldb + bcol);
+            }
+            return;
+        }
 #pragma unroll
         for (int v = 0; v < 2; ++v) {
             const int t = t0 + (tid >> 5) + 8 * v;
@@ -205,8 +236,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmArgs g) {
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int v = 0; v < 2; ++v) {
-            *reinterpret_cast<f32x4*>(As + ((tid >> 5) + 8 * v) * TN_LD + q4) = (R.okt[v] && ak_ok) ? R.ra[v] : zero;
-            *reinterpret_cast<f32x4*>(Bs + ((tid >> 5) + 8 * v) * TN_LD + q4) = (R.okt[v] && bn_ok) ? R.rb[v] : zero;
+            *reinterpret_cast<f32x4*>(As + ((tid >> 5) + 8 * v) * TN_LD + q4) = (FAST || (R.okt[v] && ak_ok)) ? R.ra[v] : zero;
+            *reinterpret_cast<f32x4*>(Bs + ((tid >> 5) + 8 * v) * TN_LD + q4) = (FAST || (R.okt[v] && bn_ok)) ? R.rb[v] : zero;
         }
     };
 
@@ -398,7 +429,11 @@ int runet_gemm_nn_launch(const float* a, int lda, long sa, const float* b, long 
     GemmArgs g{};
     g.a = a; g.lda = lda; g.sa = sa; g.b = b; g.ldb = n; g.sb = sb; g.c = c; g.ldc = ldc; g.sc = sc; g.rows = rows; g.k = k; g.n = n;
     // 16-deep k-steps; the 32-deep instantiation (three 35 KB stages -> one block per CU) measured 5-10 % slower (tools/bench_gemm.py)
-    hipLaunchKernelGGL(gemm_nn_kernel<16>, dim3(cdiv(rows, 128), cdiv(n, 128), batch), dim3(256), 3 * NNCfg<16>::STAGE * sizeof(float), st, g);
+    static const bool general = getenv("RUNET_GEMM_NN_GENERAL") && atoi(getenv("RUNET_GEMM_NN_GENERAL")) != 0;      // measurement knob
+    if (!general && k % 16 == 0 && k >= 16 && n >= 4 && rows > 0)
+        hipLaunchKernelGGL((gemm_nn_kernel<16, true>), dim3(cdiv(rows, 128), cdiv(n, 128), batch), dim3(256), 3 * NNCfg<16>::STAGE * sizeof(float), st, g);
+    else
+        hipLaunchKernelGGL((gemm_nn_kernel<16, false>), dim3(cdiv(rows, 128), cdiv(n, 128), batch), dim3(256), 3 * NNCfg<16>::STAGE * sizeof(float), st, g);
     return 0;
 }
 
@@ -437,6 +472,10 @@ int runet_gemm_tn_launch(const float* a, int lda, long sa, const float* b, int l
         }
         return 0;
     }
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(cdiv(k, 128) * cdiv(n, 128), batch, cdiv(rows, rps)), dim3(256), 3 * TN_STAGE * sizeof(float), st, g);
+    static const bool general = getenv("RUNET_GEMM_TN_GENERAL") && atoi(getenv("RUNET_GEMM_TN_GENERAL")) != 0;      // measurement knob
+    if (!general && rows % BK == 0 && rps % BK == 0 && k >= 4 && n >= 4)
+        hipLaunchKernelGGL(gemm_tn_kernel<true>, dim3(cdiv(k, 128) * cdiv(n, 128), batch, cdiv(rows, rps)), dim3(256), 3 * TN_STAGE * sizeof(float), st, g);
+    else
+        hipLaunchKernelGGL(gemm_tn_kernel<false>, dim3(cdiv(k, 128) * cdiv(n, 128), batch, cdiv(rows, rps)), dim3(256), 3 * TN_STAGE * sizeof(float), st, g);
     return 0;
 }

@@ -904,6 +904,6 @@ def wino4_wgrad(x, dy, out=None, v=None, dil=1):
     if _PROFILE is not None:
         e1.record()
         fl = 2.0 * 36 * t * cin * cout
-        _PROFILE.append(("gemm_tn_kernel", 4.0 * fl, fl, e0, e1))
+        _PROFILE.append(("gemm_tn_kernel<true>" if t % 16 == 0 else "gemm_tn_kernel<false>", 4.0 * fl, fl, e0, e1))
     check(lib.runet_wino4_wgrad_output(dU, -(-t // rps), cin, cout, out.data_ptr(), stream()))
     return out
