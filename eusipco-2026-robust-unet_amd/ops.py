@@ -90,7 +90,8 @@ def bump_weight_epoch():
 
 
 def _cached(w, kind, make):
-    """make(out) -> the derived tensor (out = None: allocate; else refill that tensor in place)"""
+    """make(out) -> the derived tensor (out = None: allocate; else refill that tensor in place).  make is kept in the cache entry (for
+    prefetch_derived) and must capture the weight's raw pointer, not the tensor: the entry holds the parameter by weak reference only."""
     base = w._base if w._base is not None else w
     key = (w.data_ptr(), kind)
     tag = (base._version, WEIGHT_EPOCH, tuple(w.shape))
@@ -159,10 +160,11 @@ USE_TRANSPOSED_DGRAD = os.environ.get("RUNET_TRANSPOSED_DGRAD", "0") == "1"
 def transposed_weights(w_hwio):
     """[taps][cin][cout] -> [taps][cout][cin] (cached per optimizer step) for the *_DGRAD_T modes of runet_conv_igemm."""
     kh, kw, cin, cout = w_hwio.shape
+    wp, dev = w_hwio.data_ptr(), w_hwio.device          # the closure is kept in the cache: it must not hold the parameter alive
 
     def make(out):
-        wt = out if out is not None else torch.empty((kh, kw, cout, cin), device=w_hwio.device, dtype=torch.float32)
-        check(lib.runet_transpose_taps(w_hwio.data_ptr(), wt.data_ptr(), kh * kw, cin, cout, stream()))
+        wt = out if out is not None else torch.empty((kh, kw, cout, cin), device=dev, dtype=torch.float32)
+        check(lib.runet_transpose_taps(wp, wt.data_ptr(), kh * kw, cin, cout, stream()))
         return wt
     return _cached(w_hwio, "T", make)
 
@@ -184,11 +186,12 @@ def bf16_weights(w_hwio, transpose=False):
     prec = _PRECISION                                   # bound now: a refill ahead of use runs outside the precision context
     tdtype, tname = _LOWP[prec]
     pack_elems, pack = getattr(lib, f"runet_{tname}_pack_elems"), getattr(lib, f"runet_{tname}_pack_weights")
+    wp, dev = w_hwio.data_ptr(), w_hwio.device
 
     def make(out):
         k, n = (cout, cin) if transpose else (cin, cout)
-        buf = out if out is not None else torch.empty(pack_elems(kh * kw, k, n), device=w_hwio.device, dtype=tdtype)
-        check(pack(w_hwio.data_ptr(), buf.data_ptr(), kh * kw, cin, cout, int(transpose), stream()))
+        buf = out if out is not None else torch.empty(pack_elems(kh * kw, k, n), device=dev, dtype=tdtype)
+        check(pack(wp, buf.data_ptr(), kh * kw, cin, cout, int(transpose), stream()))
         return buf
     return _cached(w_hwio, prec + ("t" if transpose else ""), make)
 
@@ -359,10 +362,11 @@ def wino_weights(w_hwio, dgrad=False):
     """HWIO 3x3 weight -> Winograd-domain U[16][K][N] (forward: K=cin, N=cout; dgrad: rotated filter, K=cout, N=cin)."""
     _, _, cin, cout = w_hwio.shape
     k, n = (cout, cin) if dgrad else (cin, cout)
+    wp, dev = w_hwio.data_ptr(), w_hwio.device
 
     def make(out):
-        U = out if out is not None else torch.empty((16, k, n), device=w_hwio.device, dtype=torch.float32)
-        check(lib.runet_wino_weights(w_hwio.data_ptr(), U.data_ptr(), cin, cout, int(dgrad), stream()))
+        U = out if out is not None else torch.empty((16, k, n), device=dev, dtype=torch.float32)
+        check(lib.runet_wino_weights(wp, U.data_ptr(), cin, cout, int(dgrad), stream()))
         return U
     return _cached(w_hwio, "wino2d" if dgrad else "wino2", make)
 
@@ -833,10 +837,11 @@ def wino4_weights(w_hwio, dgrad=False):
     """HWIO 3x3 weight -> U[36][K][N] (forward: K=cin, N=cout; dgrad: rotated filter, K=cout, N=cin)."""
     _, _, cin, cout = w_hwio.shape
     k, n = (cout, cin) if dgrad else (cin, cout)
+    wp, dev = w_hwio.data_ptr(), w_hwio.device
 
     def make(out):
-        U = out if out is not None else torch.empty((36, k, n), device=w_hwio.device, dtype=torch.float32)
-        check(lib.runet_wino4_weights(w_hwio.data_ptr(), U.data_ptr(), cin, cout, int(dgrad), stream()))
+        U = out if out is not None else torch.empty((36, k, n), device=dev, dtype=torch.float32)
+        check(lib.runet_wino4_weights(wp, U.data_ptr(), cin, cout, int(dgrad), stream()))
         return U
     return _cached(w_hwio, "wino4d" if dgrad else "wino4", make)
 
