@@ -30,6 +30,10 @@ def grow(pool, key, nfloats, device, floor):
         if buf is not None and PIN_SCRATCH:
             _retired.append(buf)
         buf = torch.empty(max(int(nfloats), floor, 2 * buf.numel() if buf is not None else 0), device=device, dtype=torch.float32)
+        if getattr(_tls, "override", None) is not None:
+            # allocated from torch's CURRENT stream's pool while the launches are redirected to the weight-gradient stream (_on_side): tell
+            # the allocator, or a buffer dropped at the next growth could be handed out again while that stream still works on it
+            buf.record_stream(_side["active"])
         pool[key] = buf
     return buf
 
