@@ -923,13 +923,18 @@ static int wgrad1x1_rows_per_split(long P, int cin, int cout) {
     if (splits > maxs) splits = maxs;
     return (int)((cdiv(P, splits) + 15) / 16 * 16);
 }
-// OPT-IN (RUNET_WGRAD1X1_GEMM=1): the 1x1 weight gradient as one TN GEMM over the pixels (gemm.hip).  Measured (tools/conv_launches.py,
-// 16 x 256^2 step, with RUNET_GEMM_TN_DIRECT=1): 1.1-1.5x faster than wgrad_tile_kernel<1,..> standalone on every shape except the
-// narrowest outputs at full resolution (64->32 @ 256^2: 170 vs 147 us), 1.66 vs 1.93 ms over the 16 launches - and no change of the step
-// time (36.17 vs 36.18 ms): weight gradients run on the side stream, off the critical path.  Default: the tile kernel.
+// The 1x1 weight gradient as one TN GEMM over the pixels (gemm.hip: 128 x 128 LDS-ring tiles, lean loader) where both channel counts
+// fill such a tile; narrower layers stay on wgrad_tile_kernel<1,..>, whose per-tile integer address arithmetic costs it 30-77 TFLOP/s
+// on the wide ones.  Measured (tools/conv_launches.py, 16 x 256^2 step): 256->128 @ 128^2 231 -> 159 us, 512->256 @ 64^2 223 -> 155,
+// 1024->512 @ 32^2 220 -> 153, the ten wide launches 1.13 -> 0.83 ms; 128->64 / 64->128 @ 128^2 would go 89 -> 131 us (half-empty tiles).
+// The step time does not move (weight gradients run on the side stream); the GPU does 0.3 ms less work.  RUNET_WGRAD1X1_TILE=1: tile kernel
+// everywhere.  (With RUNET_GEMM_TN_DIRECT=1 the GEMM is the register-direct one, which also serves narrow outputs.)
 static bool wgrad1x1_direct(long P, int cin, int cout) {
-    static const bool on = getenv("RUNET_WGRAD1X1_GEMM") && atoi(getenv("RUNET_WGRAD1X1_GEMM")) != 0;
-    return on && P * 4 < (1L << 31) && !((long)cin * cout <= 8192 && P >= (1L << 19));
+    static const bool off = getenv("RUNET_WGRAD1X1_TILE") && atoi(getenv("RUNET_WGRAD1X1_TILE")) != 0;
+    static const bool direct = getenv("RUNET_GEMM_TN_DIRECT") && atoi(getenv("RUNET_GEMM_TN_DIRECT")) != 0;
+    if (off || P * 4 >= (1L << 31)) return false;
+    if (direct) return !((long)cin * cout <= 8192 && P >= (1L << 19));
+    return cin >= 128 && cout >= 128;
 }
 
 extern "C" long runet_conv_wgrad_workspace_floats(int n_img, int h, int w_, int cin_w, int cout, int kh, int kw) {

@@ -40,6 +40,8 @@ CASES = [
     (2, 8, 8, 256, 8, 1, 1),         # 1x1, cout 8
     (1, 64, 64, 64, 64, 3, 1),       # 256x64 tile path (P = 4096 < threshold) and more
     (2, 256, 256, 16, 64, 3, 1),     # large M: 256-row tiles
+    (2, 16, 16, 256, 128, 1, 1),     # wide 1x1: weight gradient through the TN GEMM (16-row tiles: FAST loader), SIMPLE igemm loader
+    (1, 6, 10, 128, 384, 1, 1),      # wide 1x1, 60 pixels (not a multiple of 16: the general TN loader), cout not a multiple of 128
     (2, 16, 16, 256, 128, 3, 2),     # DilatedBlock shapes: dilation through the F(4x4) sub-image path when Winograd is on
     (1, 16, 32, 128, 256, 3, 4),
 ]
@@ -255,13 +257,13 @@ def test_data_gradient_on_pre_transposed_weights_equals_the_default_path(k, dil)
 
 
 def test_opt_in_direct_gemm_paths_in_a_child_process():
-    """RUNET_GEMM_TN_DIRECT / RUNET_WGRAD1X1_GEMM (register-direct TN GEMM for the F(4x4) and 1x1 weight gradients; off by default because
-    they slow the step down from the side stream, see csrc/gemm.hip) are read once per process: the F(4x4) and generic convolution tests
-    run again in a child with both set."""
+    """RUNET_GEMM_TN_DIRECT (register-direct TN GEMM for the F(4x4) and all 1x1 weight gradients; off by default because it slows the step
+    down from the side stream, see csrc/gemm.hip) is read once per process: the F(4x4) and generic convolution tests run again in a
+    child with it set."""
     import os
     import subprocess
     import sys
-    env = dict(os.environ, RUNET_GEMM_TN_DIRECT="1", RUNET_WGRAD1X1_GEMM="1")
+    env = dict(os.environ, RUNET_GEMM_TN_DIRECT="1")
     here = os.path.abspath(__file__)
     r = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-x", "-k", "winograd_f4 or fwd_dgrad_wgrad", "-p", "no:cacheprovider"],
                        env=env, capture_output=True, text=True, timeout=600, cwd=os.path.dirname(os.path.dirname(here)))
