@@ -806,12 +806,22 @@ extern "C" int runet_transpose_taps(const float* w, float* wt, int taps, int cin
     RUNET_CHECK_LAUNCH();
 }
 
-extern "C" const char* runet_conv_igemm_kernel_name(int n_img, int h, int w_, int cout, int mode) {
-    static const char* names[2][5] = {
-        {"igemm_kernel<128, 32, 32, 32, false>", "igemm_kernel<256, 64, 64, 64, false>", "igemm_kernel<128, 64, 64, 32, false>", "igemm_kernel<128, 128, 64, 64, false>", "igemm_kernel<64, 64, 32, 32, false>"},
-        {"igemm_kernel<128, 32, 32, 32, true>", "igemm_kernel<256, 64, 64, 64, true>", "igemm_kernel<128, 64, 64, 32, true>", "igemm_kernel<128, 128, 64, 64, true>", "igemm_kernel<64, 64, 32, 32, true>"}};
+extern "C" const char* runet_conv_igemm_kernel_name(int n_img, int h, int w_, int cin, int cout, int kh, int mode) {
+    // [k-contiguous weights][SIMPLE loader][tile variant]: the names rocprofv3 prints for the instantiations runet_conv_igemm launches
+    static const char* names[2][2][5] = {
+        {{"igemm_kernel<128, 32, 32, 32, false, false>", "igemm_kernel<256, 64, 64, 64, false, false>", "igemm_kernel<128, 64, 64, 32, false, false>",
+          "igemm_kernel<128, 128, 64, 64, false, false>", "igemm_kernel<64, 64, 32, 32, false, false>"},
+         {"igemm_kernel<128, 32, 32, 32, false, true>", "igemm_kernel<256, 64, 64, 64, false, true>", "igemm_kernel<128, 64, 64, 32, false, true>",
+          "igemm_kernel<128, 128, 64, 64, false, true>", "igemm_kernel<64, 64, 32, 32, false, true>"}},
+        {{"igemm_kernel<128, 32, 32, 32, true, false>", "igemm_kernel<256, 64, 64, 64, true, false>", "igemm_kernel<128, 64, 64, 32, true, false>",
+          "igemm_kernel<128, 128, 64, 64, true, false>", "igemm_kernel<64, 64, 32, 32, true, false>"},
+         {"igemm_kernel<128, 32, 32, 32, true, true>", "igemm_kernel<256, 64, 64, 64, true, true>", "igemm_kernel<128, 64, 64, 32, true, true>",
+          "igemm_kernel<128, 128, 64, 64, true, true>", "igemm_kernel<64, 64, 32, 32, true, true>"}}};
     const bool kc = (mode == RUNET_CONV_DGRAD || mode == RUNET_CONVT_DGRAD);      // the _T modes read pre-transposed weights with the n-contiguous kernels
-    return names[kc ? 1 : 0][pick_variant((long)n_img * h * w_, cout)];
+    static const bool no_simple = getenv("RUNET_IGEMM_GENERAL") && atoi(getenv("RUNET_IGEMM_GENERAL")) != 0;
+    // SIMPLE loader (launch_igemm): 1x1 convolutions and the k2-s2 transposed convolution, K a multiple of 16
+    const bool simple = !no_simple && (kh == 1 || kh == 2) && cin % 16 == 0 && cout >= 4;
+    return names[kc ? 1 : 0][simple ? 1 : 0][pick_variant((long)n_img * h * w_, cout)];
 }
 
 extern "C" int runet_conv_igemm(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy,

@@ -295,7 +295,7 @@ def _igemm(mode, x, ldx, w, bias, y, ldy, n, h, wd, cin, cin_w, cout, kh, kw, di
     check(lib.runet_conv_igemm(x, ldx, w, bias, y, ldy, n, h, wd, cin, cin_w, cout, kh, kw, dil, mode, accumulate, stream()))
     e1.record()
     taps = 4 if kh == 2 else kh * kw
-    name = lib.runet_conv_igemm_kernel_name(n, h, wd, cout, mode).decode()
+    name = lib.runet_conv_igemm_kernel_name(n, h, wd, min(cin, cin_w), cout, kh, mode).decode()
     fl = 2.0 * n * h * wd * taps * min(cin, cin_w) * cout
     _PROFILE.append((name, fl, fl, e0, e1))
 

@@ -35,5 +35,5 @@ def test_host_side_validation_returns_error_codes_without_a_gpu():
     assert b"even" in lib.runet_last_error()
     assert lib.runet_adam_chunk_elems() > 0
     assert lib.runet_conv_wgrad_workspace_floats(16, 256, 256, 64, 64, 3, 3) > 0
-    name = lib.runet_conv_igemm_kernel_name(16, 256, 256, 64, 0)
+    name = lib.runet_conv_igemm_kernel_name(16, 256, 256, 64, 64, 3, 0)
     assert name.startswith(b"igemm_kernel<")
