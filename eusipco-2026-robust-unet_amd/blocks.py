@@ -10,6 +10,8 @@ AttentionGate :120-148 + ConvTranspose2d + torch.cat :301-303, outc :274-277, Ma
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import ops
@@ -105,6 +107,9 @@ class BNState:
         self.weight, self.bias, self.running_mean, self.running_var, self.nbt = weight, bias, running_mean, running_var, nbt
 
 
+FUSED_BN_STATS = os.environ.get("RUNET_BN_STATS_3", "0") != "1"      # RUNET_BN_STATS_3=1: statistics / combine / finalize as three launches
+
+
 def bn_coeff(x, bn: BNState, training, sm: Small, want_minmax=False, stats_hook=None):
     """Batch (training) or running (eval) statistics -> (scale, shift, save_mean, save_invstd[, per-(n,c) stats])."""
     n, h, w, c = x.shape
@@ -112,6 +117,12 @@ def bn_coeff(x, bn: BNState, training, sm: Small, want_minmax=False, stats_hook=
     st = ops.stream()
     scale, shift, mean, invstd = sm.f(c), sm.f(c), sm.f(c), sm.f(c)
     nc = None
+    if training and not want_minmax and stats_hook is None and FUSED_BN_STATS:
+        # no per-image statistics wanted: partials -> batch statistics -> coefficients in two launches
+        check(lib.runet_bn_stats(x.data_ptr(), ops.ld(x), n, hw, c, _ws(n, hw, c, x.device).data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(),
+                                 bn.running_mean.data_ptr(), bn.running_var.data_ptr(), bn.nbt.data_ptr(), BN_MOMENTUM, BN_EPS,
+                                 scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), st))
+        return scale, shift, mean, invstd, None
     if training or want_minmax:
         mean_nc, m2_nc = sm.f(n * c), sm.f(n * c)
         if want_minmax:

@@ -250,6 +250,53 @@ __global__ void bn_finalize_kernel(const float* __restrict__ mean_nc, const floa
     if (save_mean) { save_mean[c] = (float)mean; save_invstd[c] = (float)invstd; }
 }
 
+// Batch statistics straight from the per-chunk partials + the BatchNorm coefficients, in ONE launch (training mode, no per-image outputs
+// wanted: every BatchNorm of the network except the nine whose per-image max / min feed the channel attention).  Block = ONE channel:
+// each of the 256 threads Chan-combines a contiguous share of the channel's n_img * nchunks partials, a fixed binary tree over the
+// threads (8 levels) finishes, thread 0 derives scale / shift / saved statistics / running statistics as bn_finalize_kernel does.
+// Replaces chan_stats_combine + bn_finalize (two ~8 us launches, 30 times per step on the forward chain).  (With 8 channels x 32 lanes
+// per block and a serial combine of the lanes the kernel took as long as the two it replaced: the chains of double-precision divisions
+// are the cost, so they are kept short.)
+__global__ __launch_bounds__(TPB) void chan_stats_finalize_kernel(const float* __restrict__ part, int C, int nparts,
+                                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                   float* run_mean, float* run_var, long long* nbt, float momentum, float eps,
+                                                                   float* __restrict__ scale, float* __restrict__ shift,
+                                                                   float* __restrict__ save_mean, float* __restrict__ save_invstd) {
+    __shared__ double sd[3][TPB];
+    const int c = blockIdx.x, t = threadIdx.x;
+    if (c == 0 && t == 0 && nbt) *nbt += 1;
+    double n_ = 0, mean = 0, m2 = 0;
+    {
+        const int per = (nparts + TPB - 1) / TPB;
+        const int q0 = t * per, q1 = min(nparts, q0 + per);
+        for (int q = q0; q < q1; ++q) {
+            const float* o = part + ((long)q * C + c) * 3;
+            chan_combine(n_, mean, m2, o[0], o[1], o[2]);
+        }
+    }
+    sd[0][t] = n_; sd[1][t] = mean; sd[2][t] = m2;
+    __syncthreads();
+    for (int stride = TPB / 2; stride > 0; stride >>= 1) {
+        if (t < stride) {
+            chan_combine(n_, mean, m2, sd[0][t + stride], sd[1][t + stride], sd[2][t + stride]);
+            sd[0][t] = n_; sd[1][t] = mean; sd[2][t] = m2;
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        const double var = m2 / n_;
+        if (run_mean) {
+            run_mean[c] = (float)((1.0 - momentum) * run_mean[c] + momentum * mean);
+            run_var[c] = (float)((1.0 - momentum) * run_var[c] + momentum * (m2 / (n_ - 1.0)));
+        }
+        const double invstd = 1.0 / sqrt(var + (double)eps);
+        const double g = gamma ? gamma[c] : 1.0, b = beta ? beta[c] : 0.0;
+        scale[c] = (float)(g * invstd);
+        shift[c] = (float)(b - mean * g * invstd);
+        if (save_mean) { save_mean[c] = (float)mean; save_invstd[c] = (float)invstd; }
+    }
+}
+
 // Streaming kernels use a division-free layout: grid (chunks, images); a thread owns VEC consecutive channels (its per-channel
 // coefficients live in registers) and every `rows`-th pixel of its chunk, so the inner loop is loads, FMAs and one pointer add.
 template <int VEC>
@@ -552,6 +599,27 @@ extern "C" int runet_chan_stats(const float* x, int ld, int n_img, int hw, int c
         hipLaunchKernelGGL((chan_stats_combine<true>), cgrid, dim3(TPB), 0, st, workspace, c, chunks, ccw, mean_nc, m2_nc, max_nc, min_nc, imax_nc, imin_nc);
     else
         hipLaunchKernelGGL((chan_stats_combine<false>), cgrid, dim3(TPB), 0, st, workspace, c, chunks, ccw, mean_nc, m2_nc, nullptr, nullptr, nullptr, nullptr);
+    RUNET_CHECK_LAUNCH();
+}
+
+extern "C" int runet_bn_stats(const float* x, int ld, int n_img, int hw, int c, float* workspace, const float* gamma, const float* beta,
+                              float* run_mean, float* run_var, long long* num_batches_tracked, float momentum, float eps, float* scale,
+                              float* shift, float* save_mean, float* save_invstd, void* stream) {
+    RUNET_REQUIRE(x && workspace && scale && shift, "null pointer");
+    REQ_VEC(c);
+    RUNET_REQUIRE(n_img > 0 && hw > 0 && ld >= c && (long)n_img * hw > 1, "bad shape (training needs > 1 value per channel)");
+    hipStream_t st = (hipStream_t)stream;
+    const int vec = (c % 4 == 0) ? 4 : 1;
+    const int cvec = c / vec, rows = TPB / cvec;
+    const int chunks = pick_chunks(n_img, hw, c, rows);
+    const int ppc = (hw + chunks - 1) / chunks;
+    const size_t lds = ((size_t)rows * c * 3 + (c * STATS_GROUPS <= TPB ? STATS_GROUPS * c * 7 : 0)) * sizeof(float);
+    RUNET_REQUIRE(lds <= 64 * 1024, "LDS budget");
+    dim3 grid(chunks, n_img);
+    if (vec == 4) hipLaunchKernelGGL((chan_stats_partial<4, false>), grid, dim3(TPB), lds, st, x, ld, hw, c, ppc, workspace);
+    else hipLaunchKernelGGL((chan_stats_partial<1, false>), grid, dim3(TPB), lds, st, x, ld, hw, c, ppc, workspace);
+    hipLaunchKernelGGL(chan_stats_finalize_kernel, dim3(c), dim3(TPB), 0, st, workspace, c, chunks * n_img, gamma, beta,
+                       run_mean, run_var, num_batches_tracked, momentum, eps, scale, shift, save_mean, save_invstd);
     RUNET_CHECK_LAUNCH();
 }
 

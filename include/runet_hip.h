@@ -94,6 +94,13 @@ int runet_bn_finalize(const float* mean_nc, const float* m2_nc, int n_img, int c
                       float* run_mean, float* run_var, long long* num_batches_tracked, float momentum, float eps, int training,
                       float* scale, float* shift, float* save_mean, float* save_invstd, void* stream);
 
+/* runet_chan_stats + runet_bn_finalize(training) without the per-image outputs, in two launches instead of three (the forward of
+ * nn.BatchNorm2d in training mode, Main_Final.py:158,160, wherever no per-image statistics are needed): partials per chunk, then one
+ * kernel that Chan-combines all of a channel's partials and derives scale / shift / saved and running statistics. */
+int runet_bn_stats(const float* x, int ld, int n_img, int hw, int c, float* workspace, const float* gamma, const float* beta,
+                   float* run_mean, float* run_var, long long* num_batches_tracked, float momentum, float eps, float* scale,
+                   float* shift, float* save_mean, float* save_invstd, void* stream);
+
 /* y = [relu](x*scale[c] + shift[c]) [* mask_nc[n, c]]   (mask = Dropout2d keep-mask already divided by 1-p, or NULL) */
 int runet_bn_apply(const float* x, int ldx, float* y, int ldy, long pixels, int hw, int c, const float* scale, const float* shift,
                    const float* mask_nc, int relu, void* stream);
