@@ -183,11 +183,21 @@ def bn_backward(dy, x, mean, invstd, scale, sums, act=None, mask=None, out=None,
     return out
 
 
+CHAN_SUM_ON_SIDE = os.environ.get("RUNET_CHAN_SUM_MAIN", "0") != "1"
+
+
 def chan_sum(x, out):
+    """Per-channel sum over all pixels (bias gradients).  Nothing in the backward chain waits for a bias gradient, so inside the backward
+    pass (ops.wgrad_side_stream active) the two launches go to the weight-gradient stream like the weight gradients themselves."""
     n, h, w, c = x.shape
-    ws = _ws(n, h * w, c, x.device)
-    check(lib.runet_chan_sum(x.data_ptr(), ops.ld(x), n * h * w, c, ws.data_ptr(), out.data_ptr(), 0, ops.stream()))
-    return out
+
+    def run():
+        ws = _ws(n, h * w, c, x.device)
+        check(lib.runet_chan_sum(x.data_ptr(), ops.ld(x), n * h * w, c, ws.data_ptr(), out.data_ptr(), 0, ops.stream()))
+        return out
+    if CHAN_SUM_ON_SIDE and ops.side_stream() is not None:
+        return ops._on_side(run, (x, out))
+    return run()
 
 
 # =============================================================================== ResidualBlock
