@@ -146,12 +146,65 @@ def bn_coeff(x, bn: BNState, training, sm: Small, want_minmax=False, stats_hook=
     return scale, shift, mean, invstd, nc
 
 
+def bn_coeff_pair(xa, bna: BNState, xb, bnb: BNState, training, sm: Small, stats_hook=None):
+    """Two BatchNorms whose inputs are ready at the same point of the pass.  Under SyncBN their per-image statistics travel in ONE
+    all-gather (the messages are latency-bound: a ResidualBlock's shortcut with its bn1, an attention gate's W_g with its W_x); otherwise
+    two plain bn_coeff calls.  -> ((scale, shift, mean, invstd) of a, the same of b)"""
+    if stats_hook is None or not training:
+        return bn_coeff(xa, bna, training, sm)[:4], bn_coeff(xb, bnb, training, sm)[:4]
+    st = ops.stream()
+    local = []
+    for x in (xa, xb):
+        n, h, w, c = x.shape
+        mean_nc, m2_nc = sm.f(n * c), sm.f(n * c)
+        check(lib.runet_chan_stats(x.data_ptr(), ops.ld(x), n, h * w, c, _ws(n, h * w, c, x.device).data_ptr(), mean_nc.data_ptr(), m2_nc.data_ptr(),
+                                   None, None, None, None, 0, st))
+        local.append((mean_nc, m2_nc, n, c))
+    res = []
+    for x, bn, (mean_all, m2_all, n_eff) in zip((xa, xb), (bna, bnb), stats_hook.gather_stats_many(local)):
+        n, h, w, c = x.shape
+        scale, shift, mean, invstd = sm.f(c), sm.f(c), sm.f(c), sm.f(c)
+        check(lib.runet_bn_finalize(mean_all.data_ptr(), m2_all.data_ptr(), n_eff, c, h * w, bn.weight.data_ptr(), bn.bias.data_ptr(),
+                                    bn.running_mean.data_ptr(), bn.running_var.data_ptr(), bn.nbt.data_ptr(), BN_MOMENTUM, BN_EPS, 1,
+                                    scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), st))
+        res.append((scale, shift, mean, invstd))
+    return res[0], res[1]
+
+
 def bn_apply(x, scale, shift, mask=None, relu=False, out=None):
     n, h, w, c = x.shape
     if out is None:
         out = ops.empty_nhwc(n, h, w, c, x)
     check(lib.runet_bn_apply(x.data_ptr(), ops.ld(x), out.data_ptr(), ops.ld(out), n * h * w, h * w, c, scale.data_ptr(), shift.data_ptr(),
                              mask.data_ptr() if mask is not None else None, int(relu), ops.stream()))
+    return out
+
+
+def bn_bwd_reduce(dy, x, mean, invstd, scale, sums, act=None, mask=None, relu_shift=None):
+    """First half of bn_backward: the LOCAL (dgamma | dbeta) sums into `sums` [2c]."""
+    n, h, w, c = x.shape
+    hw = h * w
+    if relu_shift is not None:
+        act = None
+    actp, lda = (act.data_ptr(), ops.ld(act)) if act is not None else (None, 0)
+    rsc, rsh = (scale.data_ptr(), relu_shift.data_ptr()) if relu_shift is not None else (None, None)
+    check(lib.runet_bn_bwd_reduce(dy.data_ptr(), ops.ld(dy), x.data_ptr(), ops.ld(x), actp, lda, n, hw, c, mean.data_ptr(), invstd.data_ptr(),
+                                  mask.data_ptr() if mask is not None else None, _ws(n, hw, c, x.device).data_ptr(), sums.data_ptr(), rsc, rsh,
+                                  ops.stream()))
+
+
+def bn_bwd_apply(dy, x, mean, invstd, scale, use, m_total, act=None, mask=None, out=None, relu_shift=None):
+    """Second half: dx from the sums `use` that enter it (local, all-reduced with the global element count m_total, or zeros in eval mode)."""
+    n, h, w, c = x.shape
+    hw = h * w
+    if relu_shift is not None:
+        act = None
+    actp, lda = (act.data_ptr(), ops.ld(act)) if act is not None else (None, 0)
+    if out is None:
+        out = ops.empty_nhwc(n, h, w, c, x)
+    check(lib.runet_bn_bwd_apply(dy.data_ptr(), ops.ld(dy), x.data_ptr(), ops.ld(x), actp, lda, out.data_ptr(), ops.ld(out), n * hw, hw, c,
+                                 mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), use.data_ptr(), mask.data_ptr() if mask is not None else None,
+                                 m_total, relu_shift.data_ptr() if relu_shift is not None else None, ops.stream()))
     return out
 
 
@@ -162,25 +215,12 @@ def bn_backward(dy, x, mean, invstd, scale, sums, act=None, mask=None, out=None,
     RUNNING statistics, `mean` / `invstd` are those): BatchNorm is a per-channel affine map, dx = dy * scale with no batch-statistics
     terms, while dgamma / dbeta keep their form (sums over dy * xhat and dy).  -> dx"""
     n, h, w, c = x.shape
-    hw = h * w
-    st = ops.stream()
-    ws = _ws(n, hw, c, x.device)
-    if relu_shift is not None:
-        act = None
-    actp, lda = (act.data_ptr(), ops.ld(act)) if act is not None else (None, 0)
-    maskp = mask.data_ptr() if mask is not None else None
-    rsc, rsh = (scale.data_ptr(), relu_shift.data_ptr()) if relu_shift is not None else (None, None)
-    check(lib.runet_bn_bwd_reduce(dy.data_ptr(), ops.ld(dy), x.data_ptr(), ops.ld(x), actp, lda, n, hw, c, mean.data_ptr(), invstd.data_ptr(),
-                                  maskp, ws.data_ptr(), sums.data_ptr(), rsc, rsh, st))
-    if out is None:
-        out = ops.empty_nhwc(n, h, w, c, x)
+    bn_bwd_reduce(dy, x, mean, invstd, scale, sums, act, mask, relu_shift)
     if not training:
         use, m_total = zeros(2 * c, x.device), 0
     else:
-        use, m_total = (sums, 0) if sync is None else sync.reduce_sums(sums, n * hw)
-    check(lib.runet_bn_bwd_apply(dy.data_ptr(), ops.ld(dy), x.data_ptr(), ops.ld(x), actp, lda, out.data_ptr(), ops.ld(out), n * hw, hw, c,
-                                 mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), use.data_ptr(), maskp, m_total, rsh, st))
-    return out
+        use, m_total = (sums, 0) if sync is None else sync.reduce_sums(sums, n * h * w)
+    return bn_bwd_apply(dy, x, mean, invstd, scale, use, m_total, act, mask, out, relu_shift)
 
 
 CHAN_SUM_ON_SIDE = os.environ.get("RUNET_CHAN_SUM_MAIN", "0") != "1"
@@ -222,19 +262,25 @@ def rb_forward(x, p: RBParams, training, mask=None, save=True, stats_hook=None):
     if p.ws is not None:
         if ops._stem_case(x.shape[3], p.cin_w, c, 3) and p.ws.shape[2] == p.cin_w:
             t1, r = ops.stem_conv(x, p.w1, p.ws)       # RGB stem: conv1 and the shortcut convolution in one launch
-            ss, hs, mean_s, invstd_s, _ = bn_coeff(r, p.bns, training, sm, stats_hook=stats_hook)
+            if stats_hook is None:
+                ss, hs, mean_s, invstd_s, _ = bn_coeff(r, p.bns, training, sm)
+        elif stats_hook is not None:
+            r = ops.conv_fwd(x, p.ws)                  # SyncBN: no branch; the shortcut's statistics share bn1's message below
         else:
             # the shortcut branch (1x1 convolution + its BatchNorm statistics) runs beside conv1 .. the attention maps, joins at rb_out
             sm.f(4)                                    # the arena's buffer is allocated on the main stream
             br = ops.side_branch(stats_hook is None)
             with br:
                 r = ops.conv_fwd(x, p.ws)
-                ss, hs, mean_s, invstd_s, _ = bn_coeff(r, p.bns, training, sm, stats_hook=stats_hook)
+                ss, hs, mean_s, invstd_s, _ = bn_coeff(r, p.bns, training, sm)
     else:
         r, ss, hs, mean_s, invstd_s = x, None, None, None, None
     if t1 is None:
         t1 = ops.conv_fwd(x, p.w1, keep_v=kv1)
-    s1, h1, mean1, invstd1, _ = bn_coeff(t1, p.bn1, training, sm, stats_hook=stats_hook)
+    if p.ws is not None and stats_hook is not None:
+        (ss, hs, mean_s, invstd_s), (s1, h1, mean1, invstd1) = bn_coeff_pair(r, p.bns, t1, p.bn1, training, sm, stats_hook)
+    else:
+        s1, h1, mean1, invstd1, _ = bn_coeff(t1, p.bn1, training, sm, stats_hook=stats_hook)
     use_mask = mask if training else None
     a1 = bn_apply(t1, s1, h1, use_mask, relu=True)
     if not save:
@@ -300,10 +346,17 @@ def rb_backward(ctx, dout, sink, pre="", need_dx=True):
                            davg.data_ptr(), dmx.data_ptr(), sums2.data_ptr(), dw0p.data_ptr(), dw2p.data_ptr(), st))
     dt2 = ops.empty_nhwc(n, h, w, c, x)
     sync, tr = ctx["sync"], ctx["training"]
+    use_s = None
     if not tr:
         use2, m_total = zeros(2 * c, dev), 0
+    elif sync is None:
+        use2, m_total = sums2, 0
+    elif p.ws is not None:                   # SyncBN: the shortcut BatchNorm's sums (dv is final since rb_bwd1) share bn2's all-reduce
+        sums_s = sink.buf(pre, [("shortcut.1.weight", (c,)), ("shortcut.1.bias", (c,))])
+        bn_bwd_reduce(dv, r, ctx["mean_s"], ctx["invstd_s"], ctx["ss"], sums_s)
+        (use2, m_total), (use_s, m_s) = sync.reduce_sums_many([sums2, sums_s], [P, P])
     else:
-        use2, m_total = (sums2, 0) if sync is None else sync.reduce_sums(sums2, P)
+        use2, m_total = sync.reduce_sums(sums2, P)
     check(lib.runet_rb_bwd3(dv.data_ptr(), ops.ld(dv), t2.data_ptr(), ops.ld(t2), sa.data_ptr(), dsm.data_ptr(), amax.data_ptr(),
                             ctx["ca"].data_ptr(), davg.data_ptr(), dmx.data_ptr(), ctx["idx"].data_ptr(), ctx["mean2"].data_ptr(),
                             ctx["invstd2"].data_ptr(), ctx["s2"].data_ptr(), use2.data_ptr(), dt2.data_ptr(), ops.ld(dt2), P, hw, c, m_total, st))
@@ -319,8 +372,11 @@ def rb_backward(ctx, dout, sink, pre="", need_dx=True):
     ctx["v1"] = None
     dx = None
     if p.ws is not None:
-        sums_s = sink.buf(pre, [("shortcut.1.weight", (c,)), ("shortcut.1.bias", (c,))])
-        dr = bn_backward(dv, r, ctx["mean_s"], ctx["invstd_s"], ctx["ss"], sums_s, out=dv, sync=sync, training=tr)
+        if use_s is not None:
+            dr = bn_bwd_apply(dv, r, ctx["mean_s"], ctx["invstd_s"], ctx["ss"], use_s, m_s, out=dv)
+        else:
+            sums_s = sink.buf(pre, [("shortcut.1.weight", (c,)), ("shortcut.1.bias", (c,))])
+            dr = bn_backward(dv, r, ctx["mean_s"], ctx["invstd_s"], ctx["ss"], sums_s, out=dv, sync=sync, training=tr)
         ops.conv_wgrad(x, dr, 1, 1, cin_w=p.cin_w, out=sink.buf(pre, [("shortcut.0.weight", (1, 1, p.cin_w, c))]))
         if need_dx:
             dx = ops.conv_dgrad(dt1, p.w1)
@@ -490,8 +546,9 @@ def gate_x_branch(skip, p: UpGateParams, training, sm, stats_hook=None):
     br = ops.side_branch(stats_hook is None)
     with br:
         x1 = ops.conv_fwd(skip, p.wx, p.bx)
-        sx, hx, mean_x, invstd_x, _ = bn_coeff(x1, p.bnx, training, sm, stats_hook=stats_hook)
-    return br, x1, (sx, hx, mean_x, invstd_x)
+        # SyncBN: the statistics wait for gate_forward, where they share W_g's message
+        cx = bn_coeff(x1, p.bnx, training, sm)[:4] if stats_hook is None else None
+    return br, x1, cx
 
 
 def gate_forward(up, skip, p: UpGateParams, training, att_out, sm, stats_hook=None, xb=None):
@@ -503,9 +560,14 @@ def gate_forward(up, skip, p: UpGateParams, training, att_out, sm, stats_hook=No
     if xb is None:
         xb = gate_x_branch(skip, p, training, sm, stats_hook)
     g1 = ops.conv_fwd(up, p.wg, p.bg)
-    sg, hg, mean_g, invstd_g, _ = bn_coeff(g1, p.bng, training, sm, stats_hook=stats_hook)
-    br, x1, (sx, hx, mean_x, invstd_x) = xb
-    br.join(x1)
+    br, x1, cx = xb
+    if cx is None:
+        br.join(x1)
+        (sg, hg, mean_g, invstd_g), cx = bn_coeff_pair(g1, p.bng, x1, p.bnx, training, sm, stats_hook)
+    else:
+        sg, hg, mean_g, invstd_g, _ = bn_coeff(g1, p.bng, training, sm)
+        br.join(x1)
+    sx, hx, mean_x, invstd_x = cx
     s = torch.empty((n, h, w, 1), device=skip.device, dtype=torch.float32)
     check(lib.runet_ag_psi(g1.data_ptr(), ops.ld(g1), x1.data_ptr(), ops.ld(x1), sg.data_ptr(), hg.data_ptr(), sx.data_ptr(), hx.data_ptr(),
                            p.wpsi.data_ptr(), p.bpsi.data_ptr(), s.data_ptr(), P, f, st))
@@ -541,12 +603,21 @@ def gate_backward(gc, up, skip, p: UpGateParams, datt, dup, sink, pre=""):
     check(lib.runet_ag_bwd2(ds.data_ptr(), gc["g1"].data_ptr(), ops.ld(gc["g1"]), gc["x1"].data_ptr(), ops.ld(gc["x1"]), gc["sg"].data_ptr(),
                             gc["hg"].data_ptr(), gc["sx"].data_ptr(), gc["hx"].data_ptr(), p.wpsi.data_ptr(), dpre.data_ptr(), ops.ld(dpre),
                             ws.data_ptr(), dwpsi_db.data_ptr(), P, f, st))
-    dg1 = bn_backward(dpre, gc["g1"], gc["mean_g"], gc["invstd_g"], gc["sg"], sums_g, sync=sync, training=tr)
+    if sync is not None and tr:              # SyncBN: both BatchNorms' sums are ready here - one all-reduce
+        bn_bwd_reduce(dpre, gc["g1"], gc["mean_g"], gc["invstd_g"], gc["sg"], sums_g)
+        bn_bwd_reduce(dpre, gc["x1"], gc["mean_x"], gc["invstd_x"], gc["sx"], sums_x)
+        (use_g, m_g), (use_x, m_x) = sync.reduce_sums_many([sums_g, sums_x], [P, P])
+        dg1 = bn_bwd_apply(dpre, gc["g1"], gc["mean_g"], gc["invstd_g"], gc["sg"], use_g, m_g)
+    else:
+        dg1 = bn_backward(dpre, gc["g1"], gc["mean_g"], gc["invstd_g"], gc["sg"], sums_g, training=tr)
     ops.conv_wgrad(up, dg1, 1, 1, out=wg_b[:cg * f])
     chan_sum(dg1, wg_b[cg * f:])
     ops.conv_dgrad(dg1, p.wg, out=dup, accumulate=True)
     del dg1
-    dx1 = bn_backward(dpre, gc["x1"], gc["mean_x"], gc["invstd_x"], gc["sx"], sums_x, out=dpre, sync=sync, training=tr)
+    if sync is not None and tr:
+        dx1 = bn_bwd_apply(dpre, gc["x1"], gc["mean_x"], gc["invstd_x"], gc["sx"], use_x, m_x, out=dpre)
+    else:
+        dx1 = bn_backward(dpre, gc["x1"], gc["mean_x"], gc["invstd_x"], gc["sx"], sums_x, out=dpre, training=tr)
     ops.conv_wgrad(skip, dx1, 1, 1, out=wx_b[:c * f])
     chan_sum(dx1, wx_b[c * f:])
     ops.conv_dgrad(dx1, p.wx, out=dskip, accumulate=True)

@@ -139,27 +139,46 @@ class SyncBatchNorm:
     different function from the reference's global-batch BN).  Forward: the per-image (mean, M2) rows of all ranks are
     all-gathered and Chan-combined by `runet_bn_finalize` exactly as a single process would combine its own images.
     Backward: the two per-channel sums that enter dx are all-reduced (the parameter gradients stay local sums and are
-    averaged with everything else by the gradient all-reduce).  Messages are [2*N*C] / [2*C] floats: latency-bound."""
+    averaged with everything else by the gradient all-reduce).  Messages are [2*N*C] / [2*C] floats: latency-bound, so BatchNorms that
+    reach their statistics at the same point of the pass share one message (blocks.bn_coeff_pair; the paired backward sums)."""
 
     def __init__(self, process_group=None):
         self.group = process_group
         self.world = dist.get_world_size(process_group)
+        self.messages = 0                      # collectives issued so far (tests / tuning)
+
+    def gather_stats_many(self, items):
+        """items: [(mean_nc, m2_nc, n, c), ...] of BatchNorms whose inputs are ready at the same point -> [(mean_all, m2_all, n * world), ...]
+        from ONE all-gather.  Every rank must hold the same number of images `n` (equal slots): use drop_last / equal shards, as
+        trainer.fit does under a GradAllReducer."""
+        local = torch.cat([t.reshape(-1) for it in items for t in it[:2]])
+        flat = torch.empty(self.world * local.numel(), device=local.device, dtype=local.dtype)
+        dist.all_gather_into_tensor(flat, local, group=self.group)
+        self.messages += 1
+        rows = flat.view(self.world, local.numel())
+        out, off = [], 0
+        for _, _, n, c in items:
+            k = n * c
+            out.append((rows[:, off:off + k].reshape(-1), rows[:, off + k:off + 2 * k].reshape(-1), n * self.world))
+            off += 2 * k
+        return out
 
     def gather_stats(self, mean_nc, m2_nc, n, c):
-        """Every rank must hold the same number of images `n` (all_gather into equal slots): use drop_last / equal shards, as
-        trainer.fit does under a GradAllReducer."""
-        local = torch.cat([mean_nc.reshape(-1), m2_nc.reshape(-1)])
-        parts = [torch.empty_like(local) for _ in range(self.world)]
-        dist.all_gather(parts, local, group=self.group)
-        k = n * c
-        mean_all = torch.cat([p[:k] for p in parts])
-        m2_all = torch.cat([p[k:] for p in parts])
-        return mean_all, m2_all, n * self.world
+        return self.gather_stats_many([(mean_nc, m2_nc, n, c)])[0]
+
+    def reduce_sums_many(self, sums_list, local_counts):
+        """The (dgamma | dbeta) sums of several BatchNorm backward passes in ONE all-reduce -> [(global sums, global element count), ...]"""
+        g = torch.cat([t.reshape(-1) for t in sums_list])
+        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+        self.messages += 1
+        out, off = [], 0
+        for t, cnt in zip(sums_list, local_counts):
+            out.append((g[off:off + t.numel()], cnt * self.world))
+            off += t.numel()
+        return out
 
     def reduce_sums(self, sums, local_count):
-        g = sums.clone()
-        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
-        return g, local_count * self.world
+        return self.reduce_sums_many([sums], [local_count])[0]
 
 
 def _dense(t):

@@ -48,7 +48,7 @@ def _worker(rank, world, port, q):
     # numpy, not tensors: torch shares tensor storage through file descriptors that die with the worker
     grads = {k: p.grad.detach().cpu().contiguous().numpy() for k, p in model.named_parameters()}
     bufs = {k: b.detach().cpu().float().numpy() for k, b in model.named_buffers()}
-    q.put((rank, prob.detach().cpu().numpy(), grads, bufs))
+    q.put((rank, prob.detach().cpu().numpy(), grads, bufs, model.sync_bn_hook.messages))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -66,6 +66,9 @@ def test_two_rank_syncbn_step_equals_single_process_step(pkg, oracle):
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
+    # 40 BatchNorms: one all-gather each in the forward pass and one all-reduce each in the backward pass would be 80 messages; a
+    # ResidualBlock's shortcut shares bn1's (forward) and bn2's (backward) message, an attention gate's W_x shares W_g's: 9 + 4 fewer each way
+    assert res[0][4] == res[1][4] == 80 - 2 * 13, res[0][4]
     model = _setup(pkg, oracle, dev)
     x, y = pkg.synthetic_batch(N, SIZE, seed=SEED)
     model.set_dropout_masks(oracle.dropout_masks(N, BASE, seed=SEED))
