@@ -764,8 +764,20 @@ void launch_igemm(const IGemmArgs& a, int gz, hipStream_t st) {
 
 enum IGemmVariant { V_128x32 = 0, V_256x64 = 1, V_128x64 = 2, V_128x128 = 3, V_64x64 = 4 };
 
-IGemmVariant pick_variant(long P, int ncols) {
+int g_forced_variant = -1;      // tools/igemm_variants.py: time every tile variant on one shape (runet_igemm_force_variant)
+
+// k1: channels read by a plain 1x1 convolution (0 for every other geometry); kc: k-contiguous weights (the data gradients);
+// up2: the k2-s2 transposed convolution's data gradient
+IGemmVariant pick_variant(long P, int ncols, int k1, bool kc, bool up2 = false) {
+    if (g_forced_variant >= 0) return (IGemmVariant)g_forced_variant;
     if (ncols <= 32) return V_128x32;
+    // 1x1 convolutions are short (K / 16 steps per tile) and near the HBM / MFMA balance point: many small tiles hide the prologue and
+    // the `+=` epilogue behind other tiles better than few large ones.  Measured on the 32 1x1 launches of the 16 x 256^2 step
+    // (tools/igemm_variants.py, profiles/round2_igemm_variants.txt): 64x64 wins for every data gradient and for every forward with
+    // K <= 128 (10-30 %); from K = 256 on the forward prefers the large tiles below (weights re-read per tile start to count).
+    static const bool old_rules = getenv("RUNET_IGEMM_OLD_TILES") && atoi(getenv("RUNET_IGEMM_OLD_TILES")) != 0;      // A/B knob
+    if (!old_rules && k1 > 0 && (kc || k1 <= 128)) return V_64x64;
+    if (!old_rules && up2 && kc && ncols <= 256) return V_64x64;      // same table: 199 -> 175 us (128 -> 256 @ 64^2), 198 -> 184 us (64 -> 128 @ 128^2)
     if (ncols <= 64) return (P >= 256L * 512) ? V_256x64 : V_128x64;
     const long blocks128 = (long)cdiv(P, 128) * cdiv(ncols, 128);
     if (blocks128 >= 512 || (ncols % 128 == 0 && blocks128 >= 256)) return V_128x128;
@@ -775,7 +787,9 @@ IGemmVariant pick_variant(long P, int ncols) {
 
 template <bool KC>
 void dispatch_igemm(const IGemmArgs& a, int gz, hipStream_t st) {
-    switch (pick_variant((long)a.Nimg * a.H * a.W, a.Ncols)) {
+    const bool plain1 = a.KH == 1 && a.KW == 1 && a.a_scale == 1 && a.Hin == a.H && a.Win == a.W && a.z_taps == 0;
+    const bool up2 = a.KH == 2 && a.KW == 2 && a.z_taps == 0 && a.a_scale == 2;
+    switch (pick_variant((long)a.Nimg * a.H * a.W, a.Ncols, plain1 ? a.K : 0, KC, up2)) {
     case V_128x32: launch_igemm<128, 32, 32, 32, KC>(a, gz, st); break;
     case V_256x64: launch_igemm<256, 64, 64, 64, KC>(a, gz, st); break;
     case V_128x64: launch_igemm<128, 64, 64, 32, KC>(a, gz, st); break;
@@ -806,6 +820,12 @@ extern "C" int runet_transpose_taps(const float* w, float* wt, int taps, int cin
     RUNET_CHECK_LAUNCH();
 }
 
+extern "C" int runet_igemm_force_variant(int variant) {
+    RUNET_REQUIRE(variant >= -1 && variant <= 4, "variant: -1 (automatic) or 0..4");
+    g_forced_variant = variant;
+    return 0;
+}
+
 extern "C" const char* runet_conv_igemm_kernel_name(int n_img, int h, int w_, int cin, int cout, int kh, int mode) {
     // [k-contiguous weights][SIMPLE loader][tile variant]: the names rocprofv3 prints for the instantiations runet_conv_igemm launches
     static const char* names[2][2][5] = {
@@ -821,7 +841,8 @@ extern "C" const char* runet_conv_igemm_kernel_name(int n_img, int h, int w_, in
     static const bool no_simple = getenv("RUNET_IGEMM_GENERAL") && atoi(getenv("RUNET_IGEMM_GENERAL")) != 0;
     // SIMPLE loader (launch_igemm): 1x1 convolutions and the k2-s2 transposed convolution, K a multiple of 16
     const bool simple = !no_simple && (kh == 1 || kh == 2) && cin % 16 == 0 && cout >= 4;
-    return names[kc ? 1 : 0][simple ? 1 : 0][pick_variant((long)n_img * h * w_, cout)];
+    const bool plain1 = kh == 1 && (mode == RUNET_CONV_FWD || mode == RUNET_CONV_DGRAD || mode == RUNET_CONV_DGRAD_T);
+    return names[kc ? 1 : 0][simple ? 1 : 0][pick_variant((long)n_img * h * w_, cout, plain1 ? cin : 0, kc, mode == RUNET_CONVT_DGRAD)];
 }
 
 extern "C" int runet_conv_igemm(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy,
