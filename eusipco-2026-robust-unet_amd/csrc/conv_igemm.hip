@@ -820,6 +820,14 @@ extern "C" int runet_transpose_taps(const float* w, float* wt, int taps, int cin
     RUNET_CHECK_LAUNCH();
 }
 
+int g_lowp_forced_variant = -1;      // shared by conv_bf16.hip / conv_fp16.hip (conv_lowp.inc)
+
+extern "C" int runet_igemm_lowp_force_variant(int variant) {
+    RUNET_REQUIRE(variant >= -1 && variant <= 2, "variant: -1 (automatic) or 0..2");
+    g_lowp_forced_variant = variant;
+    return 0;
+}
+
 extern "C" int runet_igemm_force_variant(int variant) {
     RUNET_REQUIRE(variant >= -1 && variant <= 4, "variant: -1 (automatic) or 0..4");
     g_forced_variant = variant;

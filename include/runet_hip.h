@@ -52,6 +52,8 @@ int runet_transpose_taps(const float* w, float* wt, int taps, int cin, int cout,
 const char* runet_conv_igemm_kernel_name(int n_img, int h, int w_, int cin, int cout, int kh, int mode);
 /* measurement hook (tools/igemm_variants.py): force the tile variant of runet_conv_igemm, 0..4 = 128x32, 256x64, 128x64, 128x128, 64x64; -1 = automatic */
 int runet_igemm_force_variant(int variant);
+/* the same for runet_conv_igemm_bf16 / _fp16: 0..2 = 128 pixels x 32, 64, 128 output channels; -1 = automatic */
+int runet_igemm_lowp_force_variant(int variant);
 
 /* dw[kh,kw,cin_w,cout] = sum_pixels x (x) dy  (weight gradient; transposed != 0: dy is [n,2h,2w,cout]
  * and the 2x2 taps index the dy pixel).  `workspace` (>= runet_conv_wgrad_workspace_floats floats, may be

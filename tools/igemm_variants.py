@@ -30,11 +30,56 @@ SHAPES = [
 ]
 
 
+def lowp(args):
+    """The same sweep for runet_conv_igemm_bf16 / _fp16, through the ops layer (packed weights come from its cache)."""
+    ops = importlib.import_module("eusipco-2026-robust-unet_amd.ops")
+    lib, check = ops.lib, ops.check
+    dev = torch.device("cuda:0")
+    names = ["128x32", "128x64", "128x128"]
+    gain = 0.0
+    print(f"{'shape':52s} " + " ".join(f"{n:>8s}" for n in names) + "   auto -> best (us)")
+    with ops.precision(args.dtype):
+        for div, cin, cout, ldx, ldy, acc, mode in SHAPES:
+            h, n = args.size // div, args.batch
+            big = 2 * h
+            src = torch.randn((n, big if mode == 3 else h, big if mode == 3 else h, ldx), device=dev)[..., :cin]
+            dst = torch.zeros((n, big if mode == 2 else h, big if mode == 2 else h, ldy), device=dev)[..., :cout]
+            k = 2 if mode >= 2 else 1
+            w = torch.randn((k, k, cin, cout) if mode in (0, 2) else (k, k, cout, cin), device=dev) * 0.05
+            run = {0: lambda: ops.conv_fwd(src, w, out=dst, accumulate=bool(acc)), 1: lambda: ops.conv_dgrad(src, w, out=dst, accumulate=bool(acc)),
+                   2: lambda: ops.convt_fwd(src, w, out=dst), 3: lambda: ops.convt_dgrad(src, w, out=dst)}[mode]
+
+            def timeit(iters=10):
+                run()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(iters):
+                    run()
+                e1.record()
+                torch.cuda.synchronize()
+                return 1e3 * e0.elapsed_time(e1) / iters
+            ts = []
+            for v in range(3):
+                check(lib.runet_igemm_lowp_force_variant(v))
+                ts.append(timeit())
+            check(lib.runet_igemm_lowp_force_variant(-1))
+            auto = timeit()
+            best = min(range(3), key=lambda v: ts[v])
+            gain += max(0.0, auto - ts[best])
+            desc = f"{('fwd', 'dgrad', 'convT fwd', 'convT dgrad')[mode]:11s} {n}x{h}x{h} {cin:4d}->{cout:4d} ld{ldx}/{ldy}{' +=' if acc else ''}"
+            print(f"{desc:52s} " + " ".join(f"{t:8.1f}" for t in ts) + f"   {auto:7.1f} -> {ts[best]:7.1f} {names[best]}", flush=True)
+    print(f"sum of (auto - best) over these launches: {gain:.0f} us per step")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--dtype", default="f32", help="bf16 / fp16: the reduced-precision kernel's three variants (128 pixels x 32 / 64 / 128 channels)")
     args = ap.parse_args()
+    if args.dtype != "f32":
+        return lowp(args)
     ops = importlib.import_module("eusipco-2026-robust-unet_amd.ops")
     lib, check = ops.lib, ops.check
     dev = torch.device("cuda:0")
