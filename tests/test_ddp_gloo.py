@@ -80,3 +80,55 @@ def test_bucketed_allreduce_world2_equals_full_batch_gradient():
     assert buckets0[0][0] == 0 and buckets0[-1][1] == total
     assert all(a[1] == b[0] for a, b in zip(buckets0, buckets0[1:]))      # contiguous cover of the arena
     assert w0 == w1                                        # broadcast_parameters made the replicas identical
+
+
+def _syncbn_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ddp = importlib.import_module(PKG + ".ddp")
+    sb = ddp.SyncBatchNorm()
+    g = torch.Generator().manual_seed(7 + rank)
+    items = [(torch.randn(2 * 5, generator=g), torch.rand(2 * 5, generator=g), 2, 5),          # (mean_nc, m2_nc, n, c) of two BatchNorms
+             (torch.randn(2 * 3, generator=g), torch.rand(2 * 3, generator=g), 2, 3)]
+    many = sb.gather_stats_many(items)
+    single = [sb.gather_stats(*it) for it in items]
+    sums = [torch.randn(10, generator=g), torch.randn(6, generator=g)]
+    red_many = sb.reduce_sums_many(sums, [128, 128])
+    red_single = [sb.reduce_sums(s, 128) for s in sums]
+    q.put((rank, [[t.numpy() if torch.is_tensor(t) else t for t in it] for it in many],
+           [[t.numpy() if torch.is_tensor(t) else t for t in it] for it in single],
+           [(t.numpy(), c) for t, c in red_many], [(t.numpy(), c) for t, c in red_single],
+           [[t.numpy() for t in it[:2]] for it in items], [s.numpy() for s in sums], sb.messages))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_syncbn_paired_messages_world2():
+    """SyncBatchNorm's shared messages (ddp.SyncBatchNorm.gather_stats_many / reduce_sums_many; torch ops only, so they run on CPU):
+    the paired all-gather returns, per BatchNorm, every rank's per-image rows in rank order - exactly what one all-gather per BatchNorm
+    returns - and the paired all-reduce the per-BatchNorm sums; each pair costs one collective."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_syncbn_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted((q.get(timeout=240) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank in range(2):
+        _, many, single, red_many, red_single, _, _, messages = out[rank]
+        assert messages == 1 + 2 + 1 + 2               # many, 2 x single, many, 2 x single
+        for b in range(2):
+            mean_all, m2_all, n_eff = many[b]
+            assert n_eff == 4
+            np.testing.assert_array_equal(mean_all, np.concatenate([out[0][5][b][0], out[1][5][b][0]]))     # rank 0's rows, then rank 1's
+            np.testing.assert_array_equal(m2_all, np.concatenate([out[0][5][b][1], out[1][5][b][1]]))
+            np.testing.assert_array_equal(mean_all, single[b][0])
+            np.testing.assert_array_equal(m2_all, single[b][1])
+            assert single[b][2] == 4
+            np.testing.assert_allclose(red_many[b][0], out[0][6][b] + out[1][6][b], rtol=0, atol=1e-6)
+            np.testing.assert_array_equal(red_many[b][0], red_single[b][0])
+            assert red_many[b][1] == red_single[b][1] == 256
