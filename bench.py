@@ -14,7 +14,7 @@ For N > 1 the line also carries `strong` (the BASELINE metric's global batch of 
 `sync_bn` (the weak run with cross-rank BatchNorm statistics): SURVEY.md section 8(d).
 
 `--config K` selects one of BASELINE.json's five configurations (1: 2x64x64; 2: 16x256x256 - the default; 3: 4x512x512 per GPU in
-bf16; 4: DeepLabV3+ 16x256x256; 5: 1x1024x1024 per GPU, fp16 operands + loss scaling, hipGraph-captured step when single-process).
+bf16; 4: DeepLabV3+ 16x256x256; 5: 1x1024x1024 per GPU, fp16 operands + loss scaling, hipGraph-captured step incl. the RCCL all-reduces for N > 1).
 
 Extra objects on the line:
   roofline     - the dominant matrix-core kernel of the step (largest accumulated launch time).  `frac` = EXECUTED multiply-add FLOPs
@@ -86,7 +86,7 @@ def parse_args(argv=None):
     ap.add_argument("--dtype", choices=["f32", "bf16", "fp16"], default=None, help="operand type of the matrix-core kernels (accumulation, master weights, "
                     "BatchNorm statistics and the optimizer stay fp32)")
     ap.add_argument("--model", choices=["runet", "deeplab"], default=None)
-    ap.add_argument("--graph", action="store_true", help="hipGraph-captured step (single process only)")
+    ap.add_argument("--graph", action="store_true", help="hipGraph-captured step (with N > 1 the RCCL gradient all-reduces are captured with it)")
     ap.add_argument("--loss-scale", type=float, default=1024.0, help="static loss scale of the fp16 mode (ignored otherwise)")
     ap.add_argument("--sync-bn", action="store_true", help="primary run with cross-rank BatchNorm statistics (results equal the global-batch step)")
     ap.add_argument("--no-extra-runs", action="store_true", help="N > 1: skip the `strong` and `sync_bn` sub-runs")
@@ -137,14 +137,14 @@ def launch_ranks(nproc, argv):
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
 def cpu_baseline(batch, size, seed):
-    """Oracle train step on the host cores at the benchmarked batch, bounded to about 10-30 s after one warm-up step."""
+    """Oracle train step on the host cores: one warm-up + at least three timed steps on a bounded sample (<= 8 images per step, ~25 s)."""
     import torch
     oracle = importlib.import_module("oracle.robust_unet_ref")
     data = importlib.import_module(PKG + ".data")
     cores = usable_cores()
     torch.set_num_threads(cores)
-    # ~0.75 s per 256x256 image and step on 16 cores: keep warm-up + timed steps within the bound
-    n = batch if batch * (size / 256.0) ** 2 <= 16 else max(1, int(16 / (size / 256.0) ** 2))
+    # ~0.75 s per 256x256 image and step on 16 cores: half the benchmarked batch (8 images) keeps 1 warm-up + 3 timed steps near 25 s
+    n = min(batch, 8) if batch * (size / 256.0) ** 2 <= 16 else max(1, int(8 / (size / 256.0) ** 2))
     net = oracle.OracleNet(3, 1, 64, seed=seed).train()
     opt = torch.optim.Adam(net.parameters(), lr=1e-4, weight_decay=1e-4)
     x, y = data.synthetic_batch(n, size, seed=seed)
@@ -162,14 +162,15 @@ def cpu_baseline(batch, size, seed):
     step()
     warm = time.time() - t0
     log(f"cpu_baseline: warm-up {warm:.1f} s; timing ...")
-    t0 = time.time()
-    steps = 0
-    while steps < 1 or (time.time() - t0 + warm < 20.0 and steps < 8):
+    times = []
+    while len(times) < 3 or (sum(times) + warm < 20.0 and len(times) < 8):
+        t0 = time.time()
         step()
-        steps += 1
-    dt = time.time() - t0
+        times.append(time.time() - t0)
+    dt, steps = sum(times), len(times)
     return {"value": round(n * steps / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{steps} train step(s) of {n} images {size}x{size} (fwd+BCE+bwd+Adam, fp32, torch CPU ops) after 1 warm-up step"}
+            "spread": {"steps": steps, "images_per_s_min": round(n / max(times), 3), "images_per_s_max": round(n / min(times), 3)},
+            "sample": f"{steps} train steps of {n} images {size}x{size} (fwd+BCE+bwd+Adam, fp32, torch CPU ops; the benchmarked batch is {batch}) after 1 warm-up step"}
 
 
 # ------------------------------------------------------------------------------------------------ one rank
@@ -239,7 +240,7 @@ def run_rank(args):
     if use_dist:
         sync = pkg.GradAllReducer(model, sync_bn=False)
         sync.broadcast_parameters(0)
-    graph = bool(args.graph) and not use_dist
+    graph = bool(args.graph)          # under a process group the captured step carries the RCCL all-reduces (trainer.TrainStep)
     step = pkg.TrainStep(model, lr=1e-4, weight_decay=1e-4, grad_sync=sync, graph=graph, loss_scale=args.loss_scale if args.dtype == "fp16" else None)
 
     def barrier():

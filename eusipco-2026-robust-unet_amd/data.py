@@ -82,11 +82,15 @@ def rasterize_shapes(shapes, image_size):
 
 
 class CoastalDataset(Dataset):
-    def __init__(self, image_paths, label_paths, transform=None, image_size=(512, 512)):
+    """(image float32 [3, S, S], mask float32 [1, S, S]) per item, as /root/reference/Main_Final.py:28-78.  return_path=True gives the
+    variant of /root/reference/Extended_Baseline_Comparison.py:43-70, whose items carry the image path as a third element."""
+
+    def __init__(self, image_paths, label_paths, transform=None, image_size=(512, 512), return_path=False):
         self.image_paths = image_paths
         self.label_paths = label_paths
         self.transform = transform
         self.image_size = image_size
+        self.return_path = bool(return_path)
 
     def __len__(self):
         return len(self.image_paths)
@@ -97,7 +101,10 @@ class CoastalDataset(Dataset):
         image = image.resize(self.image_size, Image.LANCZOS)
         mask = np.array(Image.fromarray(mask).resize(self.image_size, Image.NEAREST))
         image = self.transform(image) if self.transform else ToTensor()(image)
-        return image, torch.from_numpy(mask).float().unsqueeze(0)
+        mask = torch.from_numpy(mask).float().unsqueeze(0)
+        if self.return_path:
+            return image, mask, self.image_paths[idx]
+        return image, mask
 
     def load_image(self, image_path):
         try:

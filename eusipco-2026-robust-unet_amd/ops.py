@@ -101,7 +101,7 @@ def _cached(w, kind, make):
     tag = (base._version, WEIGHT_EPOCH, tuple(w.shape))
     hit = _derived.get(key)
     # the weak reference pins the entry to THIS parameter tensor: another model's weight allocated later at the same address misses
-    if hit is not None and hit[0] == tag and hit[2]() is base:
+    if hit is not None and hit[0] == tag and hit[2]() is base and hit[5] == base.data_ptr():
         ev = hit[4]
         if ev is not None:                         # refilled by prefetch_derived on the side stream: order this stream behind it, once
             sid = stream()
@@ -110,7 +110,7 @@ def _cached(w, kind, make):
                 ev[1].add(sid)
         return hit[1]
     val = make(None)
-    _derived[key] = [tag, val, weakref.ref(base), make, None]
+    _derived[key] = [tag, val, weakref.ref(base), make, None, base.data_ptr()]
     return val
 
 
@@ -129,7 +129,9 @@ def prefetch_derived():
     todo = []
     for key, ent in list(_derived.items()):
         base = ent[2]()
-        if base is None:
+        if base is None or base.data_ptr() != ent[5]:
+            # parameter gone, or its storage was replaced under the surviving Parameter object (`p.data = ...`, a .to() round trip): the
+            # refill closure holds the OLD raw pointer - drop the entry, the next use rebuilds it from the live storage
             del _derived[key]
         elif (ent[0][0], ent[0][1]) != (base._version, WEIGHT_EPOCH):
             todo.append((key[1].endswith("d") or key[1].endswith("t") or key[1] == "T", ent, base))

@@ -29,23 +29,28 @@ def _binary_maps(outputs, masks):
 class TrainStep:
     """graph=True: after `graph_warmup` ordinary steps the whole step (zero_grad, forward, loss, backward, Adam: ~650 kernel launches)
     is captured once into a hipGraph and replayed; inputs are copied into static buffers.  Worth it when the step is launch-bound
-    (2 images per GPU: 12.4 ms eager); at 16 images per GPU the GPU is the bottleneck either way.  Needs static shapes, no
-    gradient all-reduce (RCCL capture is not wired up) and a FusedAdam in capturable mode (device-side step counter and
-    hyper-parameters, so LR schedulers keep working without re-capture)."""
+    (2 images per GPU: 12.4 ms eager); at 16 images per GPU the GPU is the bottleneck either way.  Needs static shapes and a
+    FusedAdam in capturable mode (device-side step counter and hyper-parameters, so LR schedulers keep working without re-capture);
+    a `grad_sync` (RCCL gradient all-reduce on the communication stream) is captured with the step."""
 
-    def __init__(self, model, lr=1e-4, weight_decay=1e-4, grad_sync=None, graph=False, graph_warmup=2, loss_scale=None):
+    def __init__(self, model, lr=1e-4, weight_decay=1e-4, grad_sync=None, graph=False, graph_warmup=2, loss_scale=None, scale_window=2000):
         """loss_scale (fp16 operands: model.set_precision("fp16")): the loss is multiplied by it before backward so that the gradients
         the data-gradient / weight-gradient kernels round to fp16 stay above its 6e-5 normal range; the fused Adam divides it out again
         (grad_scale), a device-side check finds Inf / NaN gradients and makes the optimizer skip that step without a host round trip
-        (hipGraph-capturable).  `adjust_loss_scale()` (one host sync; call it once per epoch) halves the scale after skipped steps and
-        doubles it after `scale_window` clean ones, like torch.amp.GradScaler."""
+        (hipGraph-capturable).  The scale is read from DEVICE memory by the step (a one-element tensor multiplied into the loss), so a
+        captured step follows `adjust_loss_scale()` (one host sync; call it once per epoch or every few hundred steps), which halves the
+        scale after skipped steps and doubles it after `scale_window` clean STEPS, like torch.amp.GradScaler.
+        grad_sync + graph: the bucketed RCCL all-reduces are stream-ordered work on the communication stream, which forks from and
+        joins the capturing stream through events - they are captured with the step (BASELINE.json configs[4])."""
         self.model = model
         self.optimizer = FusedAdam(model.parameters(), lr=lr, weight_decay=weight_decay)
         self.grad_sync = grad_sync
         if grad_sync is not None:
             grad_sync.attach(self.optimizer)
         self.loss_scale = float(loss_scale) if loss_scale else None
-        self.scale_window, self._clean_steps, self._seen_skips = 2000, 0, 0
+        self.scale_window, self._clean_steps, self._seen_skips = int(scale_window), 0, 0
+        self._steps, self._steps_at_adjust = 0, 0           # train steps issued (host count) / at the last adjust_loss_scale()
+        self._scale_dev = None
         if self.loss_scale is not None:
             self.optimizer.capturable = True          # step counter on the device: a skipped step must not advance the bias correction
             self._base_grad_scale = self.optimizer.grad_scale
@@ -53,13 +58,23 @@ class TrainStep:
             self._flag = None
         self.graph_mode = bool(graph)
         if self.graph_mode:
-            if grad_sync is not None:
-                raise ValueError("graph=True does not capture the RCCL gradient all-reduce; use it on single-process steps")
             self.optimizer.capturable = True
             model.grad_arena()            # gradients live at fixed addresses (views of one arena): the Adam pointer table stays valid
         self._eager_left = int(graph_warmup)
         self._graph = None
         self._static = None
+
+    def _scale_tensor(self, device):
+        """The loss scale as a device scalar (created / refreshed OUTSIDE any capture: a replayed graph reads the current value)."""
+        if self._scale_dev is None:
+            self._scale_dev = torch.tensor(self.loss_scale, device=device, dtype=torch.float32)
+            self._scale_host = self.loss_scale
+        elif self._scale_host != self.loss_scale:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("the loss scale changed during a capture")
+            self._scale_dev.fill_(self.loss_scale)
+            self._scale_host = self.loss_scale
+        return self._scale_dev
 
     def _body(self, images, masks):
         self.optimizer.zero_grad(set_to_none=True)
@@ -67,7 +82,7 @@ class TrainStep:
         if self.loss_scale is None:
             loss.backward()
         else:
-            (loss * self.loss_scale).backward()
+            (loss * self._scale_tensor(loss.device)).backward()
         if self.grad_sync is not None:
             self.grad_sync.finish()
         if self.loss_scale is not None:
@@ -81,23 +96,43 @@ class TrainStep:
         self.optimizer.step()
         return loss
 
+    def set_loss_scale(self, scale):
+        """Set the loss scale by hand (also under a captured step: the device copies are refreshed before the next replay)."""
+        if self.loss_scale is None:
+            raise RuntimeError("this TrainStep was built without loss scaling")
+        self.loss_scale = float(scale)
+        self.optimizer.grad_scale = self._base_grad_scale / self.loss_scale
+
     def adjust_loss_scale(self):
-        """Dynamic loss scale (one host sync): -> (current scale, steps skipped so far)."""
+        """Dynamic loss scale (one host sync): -> (current scale, steps skipped so far).  Clean steps are counted per TRAIN STEP (host
+        count of issued steps minus the device's skip counter), not per call; the host-side Adam step (state_dict) is corrected by the
+        skipped steps, which the device-side counter never advanced."""
         if self.loss_scale is None or self._flag is None:
             return self.loss_scale, 0
         skipped = int(self._flag[1].item())
-        if skipped > self._seen_skips:
-            self.loss_scale = max(1.0, self.loss_scale / 2.0 ** min(4, skipped - self._seen_skips))
+        new_skips = skipped - self._seen_skips
+        issued = self._steps - self._steps_at_adjust
+        self._steps_at_adjust = self._steps
+        if new_skips > 0:
+            self.loss_scale = max(1.0, self.loss_scale / 2.0 ** min(4, new_skips))
             self._clean_steps = 0
+            for st in self.optimizer.state.values():
+                if "step" in st:
+                    st["step"] = max(0, st["step"] - new_skips)
         else:
-            self._clean_steps += 1
+            self._clean_steps += max(issued, 0)
             if self._clean_steps >= self.scale_window:
                 self.loss_scale, self._clean_steps = self.loss_scale * 2.0, 0
         self._seen_skips = skipped
         self.optimizer.grad_scale = self._base_grad_scale / self.loss_scale
+        if self._scale_dev is not None:
+            self._scale_tensor(self._scale_dev.device)          # device copy of the scale: the next (replayed) step reads it
+        if self.optimizer.capturable:
+            self.optimizer.sync_hyper()
         return self.loss_scale, skipped
 
     def __call__(self, images, masks):
+        self._steps += 1
         if not self.graph_mode:
             return self._body(images, masks)
         if self._graph is not None and (images.shape != self._static[0].shape or masks.shape != self._static[1].shape):
@@ -108,16 +143,26 @@ class TrainStep:
         if self._graph is None:
             self._static = [images.clone(), masks.clone(), None]
             self.optimizer.sync_hyper()
+            if self.loss_scale is not None:
+                self._scale_tensor(images.device)
+                if self._flag is None:        # graph_warmup=0: the overflow flag must exist before the capture (it persists across replays)
+                    self._flag = torch.zeros(2, device=images.device, dtype=torch.int32)
+                    self.optimizer.skip_flag = self._flag
             torch.cuda.synchronize()
             ops.PIN_SCRATCH = True        # the graph bakes in scratch addresses: pools may grow later but never free what it uses
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # under a process group the collective library's watchdog thread polls events while this thread captures: only THIS
+            # thread's calls are checked against the capture then ("thread_local"), as torch documents for NCCL + graphs
+            mode = "thread_local" if self.grad_sync is not None else "global"
+            with torch.cuda.graph(g, capture_error_mode=mode):
                 self._static[2] = self._body(self._static[0], self._static[1])
             self._graph = g
         else:
             self._static[0].copy_(images, non_blocking=True)
             self._static[1].copy_(masks, non_blocking=True)
         self.optimizer.sync_hyper()
+        if self.loss_scale is not None:
+            self._scale_tensor(images.device)
         self._graph.replay()
         self.optimizer.advance_host_step()
         ops.bump_weight_epoch()          # the replay updated the weights: cached derived weights (eager fallback steps) are stale

@@ -40,8 +40,10 @@ class _Pool(nn.Module):
 class UNet(nn.Module):
     def __init__(self, n_channels=3, n_classes=2):
         super().__init__()
-        if not 2 <= n_classes <= 4:
-            raise ValueError("the fused head handles 2..4 classes (the reference uses 2)")
+        if not 1 <= n_classes <= 4:
+            # the reference takes any n_classes; this head is a 64 -> 4 padded 1x1 GEMM (channel quads) and ops.cross_entropy takes 2..8
+            # classes, so 1..4 run here (the reference trains 2); INTEGRATION.md states the bound
+            raise ValueError("the fused head handles 1..4 classes (the reference uses 2)")
         self.n_channels, self.n_classes = n_channels, n_classes
         self.enc1 = _conv_block(n_channels, 64)
         self.enc2 = _conv_block(64, 128)
@@ -59,6 +61,14 @@ class UNet(nn.Module):
         self.final = Conv2d(64, n_classes, 1)
         self.pool = _Pool()
         self.precision = "f32"
+
+    def __setattr__(self, name, value):
+        # ddp.GradAllReducer(sync_bn=True) / set_sync_bn(True) install a cross-rank BatchNorm hook on the model; this model's blocks use
+        # per-rank statistics only - refuse loudly instead of silently training a different function than the caller asked for
+        if name == "sync_bn_hook" and value is not None:
+            raise NotImplementedError("the plain UNet has no SyncBatchNorm path (per-rank BatchNorm statistics only): "
+                                      "construct GradAllReducer(sync_bn=False)")
+        super().__setattr__(name, value)
 
     def set_precision(self, mode):
         if mode not in ops.PRECISIONS:

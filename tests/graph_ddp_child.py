@@ -1,0 +1,51 @@
+"""Child process of tests/test_gpu_config5.py: ONE RCCL rank (backend "nccl" on ROCm), the data-parallel train step eager and captured.
+Prints GRAPH_DDP_OK when the replayed graph (which contains the bucketed all-reduces on the communication stream) leaves parameters
+bit-equal to the eager data-parallel step's."""
+import importlib
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", device_id=dev)
+    pkg = importlib.import_module("eusipco-2026-robust-unet_amd")
+    trainer = importlib.import_module("eusipco-2026-robust-unet_amd.trainer")
+    oracle = importlib.import_module("oracle.robust_unet_ref")
+    base, n, size, seed = 16, 2, 64, 11
+    st = oracle.init_state(3, 1, base, seed=seed, perturb_bn=True)
+    masks = oracle.dropout_masks(n, base, seed=seed)
+    batches = [pkg.synthetic_batch(n, size, seed=seed + i) for i in range(5)]
+    res = {}
+    for graph in (False, True):
+        m = pkg.RobustUNet(3, 1, base)
+        m.load_state_dict(st)
+        m = m.to(dev).train()
+        m.set_dropout_masks({k: v.to(dev) for k, v in masks.items()})
+        red = pkg.GradAllReducer(m, bucket_floats=200_000)          # several buckets even at base 16
+        red.broadcast_parameters(0)                                   # brings the communicator up before any capture
+        step = trainer.TrainStep(m, lr=1e-3, weight_decay=1e-4, grad_sync=red, graph=graph, graph_warmup=2)
+        step.optimizer.capturable = True
+        losses = [step(x.to(dev), y.to(dev)).detach().clone() for x, y in batches]
+        torch.cuda.synchronize()
+        assert len(red.buckets_last_step) >= 3, red.buckets_last_step
+        if graph:
+            assert step._graph is not None
+        res[graph] = (losses, [p.detach().clone() for p in m.parameters()])
+    for a, b in zip(res[False][0], res[True][0]):
+        assert torch.equal(a, b), (float(a), float(b))
+    for a, b in zip(res[False][1], res[True][1]):
+        assert torch.equal(a, b)
+    print("GRAPH_DDP_OK buckets", len(red.buckets_last_step), "loss", float(res[True][0][-1]))
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

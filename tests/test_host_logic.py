@@ -120,6 +120,12 @@ def test_dataset_is_drop_in(pkg, tmp_path):
     ds = pkg.CoastalDataset([os.path.join(d, "img", "missing.png")], [os.path.join(d, "ann", "missing.json")], image_size=(32, 32))
     img, mask = ds[0]                                                              # grey image + zero mask, as the reference
     assert img.shape == (3, 32, 32) and abs(float(img.mean()) - 128 / 255) < 1e-6 and float(mask.sum()) == 0.0
+    # the baseline-comparison script's variant: (image, mask, path) - Extended_Baseline_Comparison.py:70; a DataLoader collates the paths into a list
+    ds3 = pkg.CoastalDataset(val.dataset.image_paths, val.dataset.label_paths, transform=val.dataset.transform, image_size=(64, 64), return_path=True)
+    i3, m3, path = ds3[0]
+    assert torch.equal(i3, val.dataset[0][0]) and torch.equal(m3, val.dataset[0][1]) and path == val.dataset.image_paths[0]
+    xb, yb, pb = next(iter(torch.utils.data.DataLoader(ds3, batch_size=2)))
+    assert xb.shape == (2, 3, 64, 64) and list(pb) == val.dataset.image_paths[:2]
 
 
 def test_synthetic_batch_is_deterministic(pkg):
