@@ -293,6 +293,28 @@ extern "C" int runet_wino4_conv(const float* x, int ldx, const float* U, const f
     RUNET_CHECK_LAUNCH();
 }
 
+// The same composite with the 36 position-GEMMs on the bf16 matrix cores (gemm_split.hip: exact three-way operand split, fp32-accurate).
+// Upacked: runet_wino4_weights -> runet_gemm_x3_pack (36 matrices [k][n] -> split planes), once per optimizer step.
+extern "C" int runet_wino4_conv_x3(const float* x, int ldx, const void* Upacked, const float* bias, float* y, int ldy, int n_img, int h, int w, int k,
+                                   int n, int dil, int accumulate, float* workspace, long workspace_floats, void* stream) {
+    RUNET_REQUIRE(x && Upacked && y && workspace, "null pointer");
+    RUNET_REQUIRE(dil_ok(h, w, dil) && runet_wino4_supported(h / dil, w / dil, k, n) && k % 16 == 0,
+                  "shape not supported by the split-operand F(4x4,3x3) path (H/dil, W/dil multiples of 4; K multiple of 16, N of 4)");
+    RUNET_REQUIRE(ldx >= k && ldx % 2 == 0 && ldy >= n && ldy % 2 == 0, "pixel strides must be even and cover the channels");
+    RUNET_REQUIRE(((uintptr_t)x % 8) == 0 && ((uintptr_t)y % 8) == 0 && ((uintptr_t)Upacked % 16) == 0 && ((uintptr_t)workspace % 16) == 0 &&
+                  (!bias || ((uintptr_t)bias % 8) == 0), "alignment");
+    RUNET_REQUIRE(workspace_floats >= runet_wino4_workspace_floats(n_img, h, w, k, n), "workspace too small (runet_wino4_workspace_floats)");
+    const W4Geom g = geom(n_img, h, w, dil);
+    hipStream_t st = (hipStream_t)stream;
+    float* V = workspace;
+    float* M = workspace + 36L * g.T * k;
+    hipLaunchKernelGGL(wino4_input_kernel<0>, dim3(cdiv(g.T * (k / 2), 256)), dim3(256), 0, st, x, ldx, k, g, V);
+    const int rc = runet_gemm_x3_batched(V, k, g.T * k, Upacked, M, n, g.T * n, 36, (int)g.T, k, n, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(wino4_output_kernel, dim3(cdiv(g.T * (n / 2), 256)), dim3(256), 0, st, M, n, g, bias, y, ldy, accumulate);
+    RUNET_CHECK_LAUNCH();
+}
+
 extern "C" long runet_wino4_wgrad_workspace_floats(int n_img, int h, int w, int cin, int cout) {
     const long T = (long)n_img * (h / 4) * (w / 4);
     return 36L * T * ((long)cin + cout) + (long)cdiv(T, wgrad_rows_per_split(T, cin, cout)) * 36 * cin * cout;

@@ -839,11 +839,30 @@ def wino4_ok(h, w, k, n):
     return bool(lib.runet_wino4_supported(h, w, k, n))
 
 
+# fp32 position-GEMMs on the BF16 matrix cores: exact three-way operand split, six bf16 MFMAs per product (csrc/gemm_split.hip) - fp32-accurate
+# (errors against float64 equal to the f32-MFMA kernels', tools/bench_gemm_x3.py) at 6/16 of the matrix time.  RUNET_NO_X3=1: f32 MFMA.
+USE_X3 = os.environ.get("RUNET_NO_X3", "0") != "1"
+
+
+def _x3_case(k):
+    return USE_X3 and k % 16 == 0
+
+
 def wino4_weights(w_hwio, dgrad=False):
-    """HWIO 3x3 weight -> U[36][K][N] (forward: K=cin, N=cout; dgrad: rotated filter, K=cout, N=cin)."""
+    """HWIO 3x3 weight -> U[36][K][N] (forward: K=cin, N=cout; dgrad: rotated filter, K=cout, N=cin); under USE_X3 the split-plane
+    packing of it (runet_gemm_x3_pack: [36][3][K/8][N][8] bf16) that runet_wino4_conv_x3 / runet_gemm_x3_batched read."""
     _, _, cin, cout = w_hwio.shape
     k, n = (cout, cin) if dgrad else (cin, cout)
     wp, dev = w_hwio.data_ptr(), w_hwio.device
+    if _x3_case(k):
+        def make_x3(out):
+            U = grow(_ws4, (dev.index, "U", stream()), 36 * k * n, dev, 1)
+            check(lib.runet_wino4_weights(wp, U.data_ptr(), cin, cout, int(dgrad), stream()))
+            Up = out if out is not None else torch.empty(lib.runet_gemm_x3_pack_elems(36, k, n), device=dev, dtype=torch.bfloat16)
+            check(lib.runet_gemm_x3_pack(U.data_ptr(), k * n, Up.data_ptr(), 36, k, n, stream()))
+            Up.kn = (k, n)
+            return Up
+        return _cached(w_hwio, "wino4xd" if dgrad else "wino4x", make_x3)
 
     def make(out):
         U = out if out is not None else torch.empty((36, k, n), device=dev, dtype=torch.float32)
@@ -856,15 +875,17 @@ def wino4_conv(x, U, bias=None, out=None, accumulate=False, keep_v=None, dil=1):
     """keep_v: dict that receives {"V": transformed input [36*T*K]} - the weight gradient of the same convolution reuses it
     (conv_wgrad(..., v=...)) instead of transforming x again."""
     n, h, w, k = x.shape
-    nn_ = U.shape[2]
+    x3 = U.dtype == torch.bfloat16                      # split-plane packing (wino4_weights under USE_X3)
+    nn_ = U.kn[1] if x3 else U.shape[2]
     if out is None:
         out = empty_nhwc(n, h, w, nn_, x)
     bp = bias.data_ptr() if bias is not None else None
     t = n * (h // 4) * (w // 4)
     if _PROFILE is None and keep_v is None:
         ws = _workspace4(lib.runet_wino4_workspace_floats(n, h, w, k, nn_), x.device)
-        check(lib.runet_wino4_conv(x.data_ptr(), ld(x), U.data_ptr(), bp, out.data_ptr(), ld(out), n, h, w, k, nn_, dil, int(accumulate), ws.data_ptr(),
-                                   ws.numel(), stream()))
+        fn = lib.runet_wino4_conv_x3 if x3 else lib.runet_wino4_conv
+        check(fn(x.data_ptr(), ld(x), U.data_ptr(), bp, out.data_ptr(), ld(out), n, h, w, k, nn_, dil, int(accumulate), ws.data_ptr(),
+                 ws.numel(), stream()))
         return out
     # the same three kernels through their own entry points (V kept for the backward pass / HIP events around the position-GEMM alone)
     if keep_v is not None:
@@ -878,11 +899,15 @@ def wino4_conv(x, U, bias=None, out=None, accumulate=False, keep_v=None, dil=1):
     if _PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(lib.runet_gemm_batched(V, k, t * k, U.data_ptr(), k * nn_, M, nn_, t * nn_, 36, t, k, nn_, stream()))
+    if x3:
+        check(lib.runet_gemm_x3_batched(V, k, t * k, U.data_ptr(), M, nn_, t * nn_, 36, t, k, nn_, stream()))
+    else:
+        check(lib.runet_gemm_batched(V, k, t * k, U.data_ptr(), k * nn_, M, nn_, t * nn_, 36, t, k, nn_, stream()))
     if _PROFILE is not None:
         e1.record()
         fl = 2.0 * 36 * t * k * nn_          # the position-GEMMs' own FLOPs; the convolution they implement is 4x that in direct-conv FLOPs
-        _PROFILE.append((lib.runet_gemm_batched_kernel_name(36, t, k, nn_).decode(), 4.0 * fl, fl, e0, e1))
+        kname = lib.runet_gemm_x3_kernel_name(36, t, k, nn_) if x3 else lib.runet_gemm_batched_kernel_name(36, t, k, nn_)
+        _PROFILE.append((kname.decode(), 4.0 * fl, fl, e0, e1))
     check(lib.runet_wino4_output(M, nn_, n, h, w, dil, bp, out.data_ptr(), ld(out), int(accumulate), stream()))
     return out
 
@@ -894,7 +919,8 @@ def wino4_wgrad(x, dy, out=None, v=None, dil=1):
     if out is None:
         out = torch.empty((3, 3, cin, cout), device=x.device, dtype=torch.float32)
     ws = _workspace4(lib.runet_wino4_wgrad_workspace_floats(n, h, w, cin, cout), x.device)
-    if _PROFILE is None and v is None:
+    x3 = USE_X3 and (n * (h // 4) * (w // 4)) % 16 == 0 and cin > 64 and cout > 64
+    if _PROFILE is None and v is None and not x3:
         check(lib.runet_wino4_wgrad(x.data_ptr(), ld(x), dy.data_ptr(), ld(dy), out.data_ptr(), ws.data_ptr(), ws.numel(), n, h, w, cin, cout, dil, stream()))
         return out
     t = n * (h // 4) * (w // 4)
@@ -911,10 +937,13 @@ def wino4_wgrad(x, dy, out=None, v=None, dil=1):
     if _PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(lib.runet_gemm_tn_batched(V, cin, t * cin, Z, cout, t * cout, dU, 36, t, cin, cout, rps, stream()))
+    if x3:
+        check(lib.runet_gemm_x3_tn_batched(V, cin, t * cin, Z, cout, t * cout, dU, 36, t, cin, cout, rps, stream()))
+    else:
+        check(lib.runet_gemm_tn_batched(V, cin, t * cin, Z, cout, t * cout, dU, 36, t, cin, cout, rps, stream()))
     if _PROFILE is not None:
         e1.record()
         fl = 2.0 * 36 * t * cin * cout
-        _PROFILE.append(("gemm_tn_kernel<true>" if t % 16 == 0 else "gemm_tn_kernel<false>", 4.0 * fl, fl, e0, e1))
+        _PROFILE.append(("gemm_tn_x3_kernel" if x3 else ("gemm_tn_kernel<true>" if t % 16 == 0 else "gemm_tn_kernel<false>"), 4.0 * fl, fl, e0, e1))
     check(lib.runet_wino4_wgrad_output(dU, -(-t // rps), cin, cout, out.data_ptr(), stream()))
     return out

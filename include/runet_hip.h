@@ -212,6 +212,23 @@ int runet_gemm_tn_batched(const float* a, int lda, long stride_a, const float* b
  * fill the 256 CUs unevenly) - for matching live timings with rocprofv3 rows */
 const char* runet_gemm_batched_kernel_name(int batch, int rows, int k, int n);
 
+/* ---- the same GEMMs in fp32 on the BF16 matrix cores: exact three-way operand splitting, six bf16 MFMAs per fp32 product ("bf16x6") ----
+ * The f32-input MFMA runs at 1/16 of the bf16 MFMA rate on gfx950.  x = h + m + l with three bf16 values holds exactly for every fp32 x;
+ * six of the nine cross products are kept (the three dropped are <= 2^-23 of the product, the size of one fp32 rounding), all accumulate in
+ * fp32: an fp32-accurate GEMM at 6/16 of the matrix time (csrc/gemm_split.hip; measured against float64 in tests/test_gpu_conv.py).
+ * These serve the same role as runet_gemm_batched / runet_gemm_tn_batched (the position-GEMMs of nn.Conv2d 3x3, Main_Final.py:157,159).
+ * runet_gemm_x3_pack: B fp32 [z][k][n] (the weights side: once per optimizer step) -> packed split planes [z][3][k/8][n][8] bf16,
+ *   runet_gemm_x3_pack_elems(batch, k, n) 2-byte elements.  runet_gemm_x3_batched: C[z][rows][n] = A[z][rows][k] . B[z] with A fp32 split on
+ *   the fly (k % 16 == 0).  runet_gemm_x3_tn_batched: as runet_gemm_tn_batched, both operands fp32 (rows, rows_per_split multiples of 16). */
+int runet_gemm_x3_supported(int rows, int k, int n);
+long runet_gemm_x3_pack_elems(int batch, int k, int n);
+int runet_gemm_x3_pack(const float* b, long stride_b, void* packed, int batch, int k, int n, void* stream);
+int runet_gemm_x3_batched(const float* a, int lda, long stride_a, const void* packed_b, float* c, int ldc, long stride_c, int batch, int rows,
+                          int k, int n, void* stream);
+int runet_gemm_x3_tn_batched(const float* a, int lda, long stride_a, const float* b, int ldb, long stride_b, float* c, int batch, int rows, int k,
+                             int n, int rows_per_split, void* stream);
+const char* runet_gemm_x3_kernel_name(int batch, int rows, int k, int n);
+
 /* ---- Winograd F(4x4,3x3), unfused, for the deep 3x3 convolutions (Main_Final.py:157,159 at >= 256 channels) and their autograd ----
  * U [36][K][N] from runet_wino4_weights (dgrad != 0: rotated filter, K = cout, N = cin).  conv: x [n,h,w,K] -> y [n,h,w,N] ('same'), H, W % 4 == 0.
  * dil >= 1 (padding = dil: the bottleneck's DilatedBlock, Main_Final.py:207-208): the dilated convolution is run as dil*dil independent
@@ -222,6 +239,9 @@ long runet_wino4_workspace_floats(int n_img, int h, int w, int k, int n);
 int runet_wino4_weights(const float* w_hwio, float* U, int cin, int cout, int dgrad, void* stream);
 int runet_wino4_conv(const float* x, int ldx, const float* U, const float* bias, float* y, int ldy, int n_img, int h, int w, int k, int n,
                      int dil, int accumulate, float* workspace, long workspace_floats, void* stream);
+/* runet_wino4_conv with the position-GEMMs on the bf16 matrix cores (split operands, fp32-accurate): Upacked = runet_gemm_x3_pack of U; k % 16 == 0 */
+int runet_wino4_conv_x3(const float* x, int ldx, const void* Upacked, const float* bias, float* y, int ldy, int n_img, int h, int w, int k, int n,
+                        int dil, int accumulate, float* workspace, long workspace_floats, void* stream);
 /* the stages of the two composites below, one kernel each (T = n_img*(h/4)*(w/4) tiles):
  *   runet_wino4_input  mode 0: V[36][T][c] = B^T d B (6x6 patches of src, stride 4, 1-pixel halo); mode 1: Z[36][T][c] = A dY A^T (4x4 tiles)
  *   runet_gemm_batched / runet_gemm_tn_batched: the 36 position-GEMMs

@@ -71,18 +71,24 @@ def test_config5_fp16_graph_step_against_the_oracle(pkg, oracle):
     rp, rl = oracle.forward(P, x, True, masks)
     rloss = oracle.bce_mean(rp, y)
     rloss.backward()
-    loss = res[True][0][0]
+    loss = res[True][0][0].detach()
     lscale = float(rl.detach().abs().max())
     lerr = float((logit.cpu() - rl.detach()).abs().max())
     perr = float((prob.cpu() - rp.detach()).abs().max())
     g = torch.cat([res[True][4][k].reshape(-1) for k in names])
     r = torch.cat([P[k].grad.double().reshape(-1) for k in names])
     cos = float((g @ r) / (g.norm() * r.norm()))
-    gn = np.array([float(res[True][4][k].norm()) for k in names])
-    rn = np.array([float(P[k].grad.double().norm()) for k in names])
+    # per-tensor norms.  A bias in front of a BatchNorm (the attention gates' W_g.0 / W_x.0 / psi.0, the DilatedBlock's conv biases) has an
+    # analytically ZERO gradient - BatchNorm removes the mean it adds - so what either side computes there is rounding noise of a
+    # cancelling sum; those tensors are left out of the norm statistic (they are inside the cosine, where they weigh nothing)
+    zero_grad = [k for k in names if (k.startswith("att") and k.endswith(".0.bias")) or (k.startswith("bottleneck.1.conv") and k.endswith(".bias"))]
+    keep = [k for k in names if k not in zero_grad]
+    gn = np.array([float(res[True][4][k].norm()) for k in keep])
+    rn = np.array([float(P[k].grad.double().norm()) for k in keep])
     rel = np.abs(gn - rn) / np.maximum(rn, 1e-30)
+    worst = keep[int(rel.argmax())]
     print(f"\nconfig 5 (1 x 1024^2 fp16, scale {scale:g}, hipGraph): loss {float(loss):.5f} vs oracle {float(rloss):.5f}; logit err {lerr:.3e} of scale "
-          f"{lscale:.2f}; prob err {perr:.3e}; gradient cosine {cos:.6f}; grad-norm rel err 50/90/100 %: {np.percentile(rel, [50, 90, 100])}")
+          f"{lscale:.2f}; prob err {perr:.3e}; gradient cosine {cos:.6f}; grad-norm rel err 50/90/100 %: {np.percentile(rel, [50, 90, 100])} (worst {worst}, {len(zero_grad)} zero-gradient biases left out)")
     # fp16 keeps 11 significant bits.  Stated bands (same as the 2 x 64^2 fp16 test, tests/test_gpu_bf16.py): loss within 0.2 % + two
     # BCE-clamp quanta (a pixel rounding to p == 1.0 against label 0 costs 100 / numel), logits within 0.5 % of their scale, gradient
     # cosine >= 0.995, per-tensor gradient norms: median within 1 %, none off by more than its own size
