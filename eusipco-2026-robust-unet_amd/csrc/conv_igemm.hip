@@ -975,6 +975,11 @@ static bool wgrad1x1_direct(long P, int cin, int cout) {
     if (direct) return !((long)cin * cout <= 8192 && P >= (1L << 19));
     return cin >= 128 && cout >= 128;
 }
+// ... and of those the ones the split-operand TN GEMM (gemm_split.hip, BF16 matrix cores, fp32-accurate) takes: pixel count a multiple of 16
+static bool wgrad1x1_x3(long P, int cin, int cout) {
+    static const bool off = (getenv("RUNET_NO_X3") && atoi(getenv("RUNET_NO_X3")) != 0) || (getenv("RUNET_GEMM_TN_DIRECT") && atoi(getenv("RUNET_GEMM_TN_DIRECT")) != 0);
+    return !off && P % 16 == 0;
+}
 
 extern "C" long runet_conv_wgrad_workspace_floats(int n_img, int h, int w_, int cin_w, int cout, int kh, int kw) {
     if (kh == 1 && kw == 1) {
@@ -1024,7 +1029,9 @@ extern "C" int runet_conv_wgrad(const float* x, int ldx, const float* dy, int ld
         const int splits = cdiv(P, rps);
         const long wsize = (long)cin * cout;
         RUNET_REQUIRE(splits == 1 || (workspace && workspace_floats >= splits * wsize), "workspace too small (runet_conv_wgrad_workspace_floats)");
-        const int rc = runet_gemm_tn_launch(x, ldx, 0, dy, ldy, 0, splits > 1 ? workspace : dw, 1, (int)P, cin, cout, rps, st);
+        const int rc = wgrad1x1_x3(P, cin, cout)
+                           ? runet_gemm_x3_tn_batched(x, ldx, 0, dy, ldy, 0, splits > 1 ? workspace : dw, 1, (int)P, cin, cout, rps, stream)
+                           : runet_gemm_tn_launch(x, ldx, 0, dy, ldy, 0, splits > 1 ? workspace : dw, 1, (int)P, cin, cout, rps, st);
         if (rc) return rc;
         if (splits > 1) hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(wsize, 32 * 4)), dim3(256), 0, st, workspace, dw, wsize, splits);
         RUNET_CHECK_LAUNCH();

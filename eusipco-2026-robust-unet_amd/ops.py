@@ -346,6 +346,56 @@ def stem_conv(x, w3, w1=None):
     return y3, y1
 
 
+# ---- 1x1 convolutions and the k2-s2 transposed convolution on the BF16 matrix cores (csrc/conv_x3.hip: the split-operand scheme of the
+# F(4x4) position GEMMs behind the SIMPLE geometry of the implicit GEMM): fp32-accurate, the weight pre-split once per optimizer step.
+# RUNET_NO_CONV_X3=1 (or RUNET_NO_X3=1): the f32-MFMA implicit GEMM everywhere.
+# Where it pays (tools/conv_launches.py, 16 x 256^2 step, single stream, x3 vs f32-MFMA igemm in us): the contraction (taps x channels) must be
+# deep enough for the matrix time to matter - K >= 256: 1x1 forward 512->256 @ 64^2 194 -> 118, 1024->512 @ 32^2 157 -> 104, transposed forward
+# 1024->512 @ 16^2 180 -> 104, transposed data gradient 256->512 @ 32^2 159 -> 104, `+=` data gradient 512->1024 @ 32^2 183 -> 123; K = 128 only
+# with >= 128 output channels (128->256 @ 64^2 59 -> 52; 128->64 @ 128^2 61 -> 73 loses); K = 64 launches are bound by streaming their
+# activations and the smaller f32 tiles keep more loads in flight (64->32 @ 256^2 95 -> 175): those stay on the implicit GEMM.
+USE_CONV_X3 = os.environ.get("RUNET_NO_CONV_X3", "0") != "1"
+CONV_X3_MIN_K = int(os.environ.get("RUNET_CONV_X3_MIN_K", "128"))        # smallest contraction (taps x channels); from 2x this on: any width
+CONV_X3_WIDE_N = int(os.environ.get("RUNET_CONV_X3_WIDE_N", "128"))      # output channels needed while the contraction is below 2x MIN_K
+_X3_KIND = {CONV_FWD: "cx3f", CONV_DGRAD: "cx3d", CONVT_FWD: "cx3uf", CONVT_DGRAD: "cx3ud"}      # "...d": refilled with the backward kinds
+
+
+def _conv_x3_case(x, cin, cin_w, cout, taps=1):
+    """taps: taps inside the contraction (4 for the transposed data gradient, else 1)."""
+    k = cin * taps
+    return (USE_X3 and USE_CONV_X3 and _PRECISION == "f32" and cin_w == cin and cin % 16 == 0 and cout % 4 == 0 and k >= CONV_X3_MIN_K
+            and (k >= 2 * CONV_X3_MIN_K or cout >= CONV_X3_WIDE_N) and ld(x) % 4 == 0 and x.data_ptr() % 16 == 0)
+
+
+def conv_x3_weights(w_hwio, mode):
+    """The module's forward weight (1x1 [1,1,Ci,Co] or transposed [2,2,Ci,Co]) -> split planes for runet_conv_x3 in `mode`."""
+    _, _, ci, co = w_hwio.shape
+    k, n = (co, ci) if mode in (CONV_DGRAD, CONVT_DGRAD) else (ci, co)
+    wp, dev = w_hwio.data_ptr(), w_hwio.device
+
+    def make(out):
+        buf = out if out is not None else torch.empty(lib.runet_conv_x3_pack_elems(k, n, mode), device=dev, dtype=torch.bfloat16)
+        check(lib.runet_conv_x3_pack(wp, buf.data_ptr(), k, n, mode, stream()))
+        return buf
+    return _cached(w_hwio, _X3_KIND[mode], make)
+
+
+def _conv_x3(mode, x, w_hwio, bias, out, n, h, w, cin, cout, accumulate):
+    """h, w: the image the 1x1 convolution runs over; the low-resolution side for the transposed modes."""
+    wp = conv_x3_weights(w_hwio, mode)
+    prof = _PROFILE is not None
+    if prof:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(lib.runet_conv_x3(x.data_ptr(), ld(x), wp.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(), ld(out), n, h, w,
+                            cin, cout, mode, int(accumulate), stream()))
+    if prof:
+        e1.record()
+        fl = 2.0 * n * h * w * (4 if mode in (CONVT_FWD, CONVT_DGRAD) else 1) * cin * cout
+        _PROFILE.append((lib.runet_conv_x3_kernel_name(n, h, w, cout, mode).decode(), fl, fl, e0, e1))
+    return out
+
+
 def conv_fwd(x, w_hwio, bias=None, out=None, dil=1, accumulate=False, keep_v=None):
     n, h, w, cin = x.shape
     kh, kw, cin_w, cout = w_hwio.shape
@@ -359,6 +409,8 @@ def conv_fwd(x, w_hwio, bias=None, out=None, dil=1, accumulate=False, keep_v=Non
         return wino_conv(x, wino_weights(w_hwio), bias, out=out, accumulate=accumulate)
     if out is None:
         out = empty_nhwc(n, h, w, cout, x)
+    if kh == 1 and _conv_x3_case(x, cin, cin_w, cout):
+        return _conv_x3(CONV_FWD, x, w_hwio, bias, out, n, h, w, cin, cout, accumulate)
     _igemm(CONV_FWD, x.data_ptr(), ld(x), w_hwio.data_ptr(), bias.data_ptr() if bias is not None else None,
            out.data_ptr(), ld(out), n, h, w, cin, cin_w, cout, kh, kw, dil, int(accumulate))
     return out
@@ -413,6 +465,8 @@ def conv_dgrad(dy, w_hwio, out=None, dil=1, accumulate=False):
         return wino_conv(dy, wino_weights(w_hwio, dgrad=True), None, out=out, accumulate=accumulate)
     if out is None:
         out = empty_nhwc(n, h, w, cin, dy)
+    if kh == 1 and _conv_x3_case(dy, cout, cout, cin):
+        return _conv_x3(CONV_DGRAD, dy, w_hwio, None, out, n, h, w, cout, cin, accumulate)
     if USE_TRANSPOSED_DGRAD:
         _igemm(CONV_DGRAD_T, dy.data_ptr(), ld(dy), transposed_weights(w_hwio).data_ptr(), None, out.data_ptr(), ld(out), n, h, w,
                cout, cout, cin, kh, kw, dil, int(accumulate))
@@ -602,6 +656,8 @@ def convt_fwd(x, w_hwio, bias=None, out=None):
         out = empty_nhwc(n, 2 * h, 2 * w, cout, x)
     if _bf16_case(cin, cin_w):
         return _igemm_bf16(CONVT_FWD, x, w_hwio, bias, out, n, h, w, cin, cout, 2, 2, 1, False, False)
+    if _conv_x3_case(x, cin, cin_w, cout):
+        return _conv_x3(CONVT_FWD, x, w_hwio, bias, out, n, h, w, cin, cout, False)
     _igemm(CONVT_FWD, x.data_ptr(), ld(x), w_hwio.data_ptr(), bias.data_ptr() if bias is not None else None,
            out.data_ptr(), ld(out), n, h, w, cin, cin_w, cout, 2, 2, 1, 0)
     return out
@@ -615,6 +671,8 @@ def convt_dgrad(dy, w_hwio, out=None, accumulate=False):
         out = empty_nhwc(n, h, w, cin, dy)
     if _bf16_case(cout, cout):
         return _igemm_bf16(CONVT_DGRAD, dy, w_hwio, None, out, n, h, w, cout, cin, 2, 2, 1, accumulate, True)
+    if _conv_x3_case(dy, cout, cout, cin, taps=4):
+        return _conv_x3(CONVT_DGRAD, dy, w_hwio, None, out, n, h, w, cout, cin, accumulate)
     if USE_TRANSPOSED_DGRAD:
         _igemm(CONVT_DGRAD_T, dy.data_ptr(), ld(dy), transposed_weights(w_hwio).data_ptr(), None, out.data_ptr(), ld(out), n, h, w,
                cout, cout, cin, 2, 2, 1, int(accumulate))

@@ -229,6 +229,19 @@ int runet_gemm_x3_tn_batched(const float* a, int lda, long stride_a, const float
                              int n, int rows_per_split, void* stream);
 const char* runet_gemm_x3_kernel_name(int batch, int rows, int k, int n);
 
+/* ---- nn.Conv2d(k=1) (Main_Final.py:126,131,172,205) and nn.ConvTranspose2d(k=2, s=2) (:261-270), forward and data gradient, by the same
+ * split-operand scheme (csrc/conv_x3.hip): same modes and argument meaning as runet_conv_igemm (RUNET_CONV_FWD, RUNET_CONV_DGRAD,
+ * RUNET_CONVT_FWD, RUNET_CONVT_DGRAD; cin = channels READ in that mode, cout = channels WRITTEN; h, w = the image the 1x1 convolution runs
+ * over, for the transposed modes the low-resolution side), but the weight comes pre-split: runet_conv_x3_pack turns the module's forward
+ * weight (HWIO: [cin][cout], transposed [2][2][Ci][Co]; the data-gradient modes read it transposed) into runet_conv_x3_pack_elems 2-byte
+ * elements, once per optimizer step.  cin % 16 == 0, cout % 4 == 0, ldx % 4 == 0, x 16-byte aligned. */
+int runet_conv_x3_supported(int cin, int cout, int mode);
+long runet_conv_x3_pack_elems(int cin, int cout, int mode);
+int runet_conv_x3_pack(const float* w, void* packed, int cin, int cout, int mode, void* stream);
+int runet_conv_x3(const float* x, int ldx, const void* wpacked, const float* bias, float* y, int ldy, int n_img, int h, int w, int cin, int cout,
+                  int mode, int accumulate, void* stream);
+const char* runet_conv_x3_kernel_name(int n_img, int h, int w, int cout, int mode);
+
 /* ---- Winograd F(4x4,3x3), unfused, for the deep 3x3 convolutions (Main_Final.py:157,159 at >= 256 channels) and their autograd ----
  * U [36][K][N] from runet_wino4_weights (dgrad != 0: rotated filter, K = cout, N = cin).  conv: x [n,h,w,K] -> y [n,h,w,N] ('same'), H, W % 4 == 0.
  * dil >= 1 (padding = dil: the bottleneck's DilatedBlock, Main_Final.py:207-208): the dilated convolution is run as dil*dil independent

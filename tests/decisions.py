@@ -12,6 +12,13 @@ checked in two parts:
      tensor; the oracle's maximum within a hair of the value at the HIP step's winner);
   2. with the oracle evaluated under the HIP step's own decisions (`forced=`), every gradient tensor must agree tightly.
 
+One more decision sits at the very end: fp32 sigmoid SATURATES (p == 1.0 exactly from logit 17.33 on) and ATen's BCELoss backward
+(p - y) / max(p (1 - p), 1e-12) followed by the sigmoid backward p (1 - p) gives d loss / d logit = 0 at a saturated pixel with label 0 but
+1 / n one ulp below it - the largest per-pixel gradient there is.  At the fan_out-normal initialisation ~4 % of the pixels are saturated,
+so at 1024 x 1024 a few pixels sit within rounding distance of that edge, and ONE of them going the other way moves every deep
+gradient tensor by ~1e-3 of its scale (a sum of ~1e6 terms of random sign, each <= 1 / n).  Such flips must be within 4 ulp of 1.0 in the
+oracle; the forced evaluation takes the HIP step's probability (value and p (1 - p) factor) at exactly those pixels.
+
 The HIP step's decisions are read from what its forward pass saves for the backward (activations, pool index bytes, attention
 arg-max vectors) and, for the AttentionGate's ReLU, from the zero pattern of the gradient its backward kernel produces.
 """
@@ -29,6 +36,29 @@ GATES = ("att4", "att3", "att2", "att1")
 PKG_NAME = "eusipco-2026-robust-unet_amd"
 # a conv bias in front of a train-mode BatchNorm has an analytically zero gradient: both sides hold rounding noise
 ZERO_GRAD_BIAS = tuple(f"bottleneck.1.conv{i}.bias" for i in (1, 2, 3, 4)) + tuple(f"{a}.{m}.0.bias" for a in GATES for m in ("W_g", "W_x", "psi"))
+
+
+# |p_hip - p_oracle| allowed where exactly one of the two is saturated (p == 1.0 or p == 0.0): 4 ulp of 1.0, expressed through NEAR_TIE
+SAT_SCALE = 4 * 2.0 ** -24 / NEAR_TIE
+
+
+class _ForcedProb(torch.autograd.Function):
+    """sigmoid(logit) whose value AND derivative factor p (1 - p) come from `p_forced` where `where` is set (the HIP step's saturation state)."""
+
+    @staticmethod
+    def forward(ctx, logit, prob, p_forced, where):
+        out = torch.where(where, p_forced, prob)
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        out, = ctx.saved_tensors
+        return g * out * (1 - out), None, None, None
+
+
+def _saturated(p):
+    return (p == 1.0) | (p == 0.0)
 
 
 def _masked(x, mask):
@@ -135,10 +165,16 @@ def oracle_step(oracle, st, masks, x, y, forced=None, training=True):
     oracle.F, oracle.residual_block, oracle.dilated_block, oracle.spatial_attention, oracle.attention_gate = rec, rb, dil, sa, gate
     try:
         prob, logit = oracle.forward(P, x, training, masks if training else None)
+        pf = rec.forced.get("prob")
+        if pf is not None:       # the HIP step's sigmoid-saturation decisions (module docstring)
+            where = _saturated(pf) != _saturated(prob.detach())
+            if bool(where.any()):
+                prob = _ForcedProb.apply(logit, prob, pf, where)
         oracle.bce_mean(prob, y).backward()
     finally:
         oracle.F, oracle.residual_block, oracle.dilated_block, oracle.spatial_attention, oracle.attention_gate = real
     named["pool"] = [e for e in rec.log if e[0] == "maxpool"]
+    named["prob"] = prob.detach().clone()
     # bias gradient of each transposed convolution re-summed in float64, and the sum of the magnitudes of its terms
     named["up_bias"] = {f"up{lvl}.bias": (u.grad.double().sum((0, 2, 3)), u.grad.double().abs().sum((0, 2, 3))) for lvl, u in zip((4, 3, 2, 1), rec.ups)}
     return {k: P[k].grad for k in pn}, named, prob.detach(), logit.detach()
@@ -185,6 +221,7 @@ def hip_step(model, x, y, dev=None):
     finally:
         model_mod.net_backward, blocks.bn_backward = real_back, real_bn
     torch.cuda.synchronize()
+    dec["prob"] = prob.detach().cpu()
     return dec, prob.detach().cpu(), logit.detach().cpu()
 
 
@@ -201,7 +238,7 @@ def forced_from_hip(dec, masks):
     for name, m in dec["gate"].items():
         # a pixel whose row of the gate gradient is all zero tells nothing (ds == 0 there, or every channel off): oracle's own decision
         relu[name] = {"last": (m, m.any(dim=1, keepdim=True).expand_as(m))}
-    return {"relu": relu, "pool": dec["pool"], "sa": dec["sa"], "ca": dec["ca"]}
+    return {"relu": relu, "pool": dec["pool"], "sa": dec["sa"], "ca": dec["ca"], "prob": dec.get("prob")}
 
 
 def differing_decisions(dec, named, masks):
@@ -237,6 +274,11 @@ def differing_decisions(dec, named, masks):
             for pos in (hip_idx != ref_idx).nonzero():
                 n_, c_ = (int(p) for p in pos)
                 flips.append((pre, "ca global max", (n_, c_), float(flat[n_, c_, ref_idx[n_, c_]] - flat[n_, c_, hip_idx[n_, c_]]), float(vals.abs().max())))
+    if dec.get("prob") is not None and named.get("prob") is not None:
+        ph, pr = dec["prob"], named["prob"]
+        for pos in (_saturated(ph) != _saturated(pr)).nonzero():
+            pos = tuple(int(p) for p in pos)
+            flips.append(("outc", "sigmoid saturation", pos, abs(float(ph[pos]) - float(pr[pos])), SAT_SCALE))
     for lvl, e in enumerate(named["pool"], 1):
         ref_flat, vals = e[1], e[2]             # ATen indices: flat h * W + w of the input plane
         n, c, h, w = vals.shape

@@ -43,3 +43,30 @@ def test_forcing_own_decisions_is_the_identity_and_a_flip_is_not(pkg, oracle):
         assert len(flips) == 1 and flips[0][3] >= 0.0
         g2, _, _, _ = D.oracle_step(oracle, st, masks, x, y, forced=D.forced_from_hip(d2, None))
         assert max(float((g0[k] - g2[k]).abs().max()) for k in g0) > 0.0, kind
+
+
+def test_sigmoid_saturation_is_a_decision(pkg, oracle):
+    """Forcing the oracle's own probabilities changes nothing; un-saturating ONE saturated pixel (p = 1.0 -> 1 - 2^-24 against label 0) is
+    listed as a near-tie flip and moves the gradients by that pixel's 1 / n."""
+    base, n, size, seed = 16, 2, 32, 3
+    st = oracle.init_state(3, 1, base, seed=seed, perturb_bn=True)
+    for k in st:                       # push the logits into saturation: a large output bias
+        if k == "outc.0.bias":
+            st[k] = st[k] + 30.0
+    masks = oracle.dropout_masks(n, base, seed=seed)
+    x, y = pkg.synthetic_batch(n, size, seed=seed)
+    g0, named, prob, _ = D.oracle_step(oracle, st, masks, x, y)
+    sat = ((prob == 1.0) & (y == 0)).nonzero()
+    assert len(sat) > 0, "no saturated pixel with label 0: the case needs a larger bias"
+    dec = _own_decisions(named, n)
+    dec["prob"] = prob.clone()
+    assert D.differing_decisions(dec, named, None) == []
+    g1, _, _, _ = D.oracle_step(oracle, st, masks, x, y, forced=D.forced_from_hip(dec, None))
+    assert max(float((g0[k] - g1[k]).abs().max()) for k in g0) == 0.0
+    pos = tuple(int(v) for v in sat[0])
+    dec["prob"][pos] = 1.0 - 2.0 ** -24
+    flips = D.differing_decisions(dec, named, None)
+    assert len(flips) == 1 and flips[0][1] == "sigmoid saturation" and flips[0][3] <= D.NEAR_TIE * flips[0][4]
+    g2, _, _, _ = D.oracle_step(oracle, st, masks, x, y, forced=D.forced_from_hip(dec, None))
+    db = float((g2["outc.0.bias"] - g0["outc.0.bias"]).abs().max())
+    assert abs(db - 1.0 / prob.numel()) <= 1e-3 / prob.numel(), db      # d loss / d logit of that pixel went from 0 to (1 - 2^-24) / n

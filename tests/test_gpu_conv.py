@@ -268,3 +268,93 @@ def test_opt_in_direct_gemm_paths_in_a_child_process():
     r = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-x", "-k", "winograd_f4 or fwd_dgrad_wgrad", "-p", "no:cacheprovider"],
                        env=env, capture_output=True, text=True, timeout=600, cwd=os.path.dirname(os.path.dirname(here)))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("rows,k,n,scale", [(256, 64, 64, 1.0), (200, 48, 36, 1.0), (1024, 512, 256, 1e-9), (130, 1024, 132, 1.0), (4096, 16, 128, 1e4)])
+def test_split_operand_gemms_against_float64(rows, k, n, scale):
+    """csrc/gemm_split.hip: the fp32 position GEMMs on the BF16 matrix cores (x = h + m + l, six bf16 products) are fp32-accurate - error
+    against a float64 product of the same operands within 4e-6 of the result's scale (the f32-MFMA kernels: the same), also for tiny and
+    large operands (the split keeps fp32's exponent range), ragged rows / columns, and the TN form with split-K slabs."""
+    L = importlib.import_module("eusipco-2026-robust-unet_amd._lib")
+    lib, check = L.lib, L.check
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    B = 3
+    g = torch.Generator().manual_seed(rows + k + n)
+    a = (torch.randn(B, rows, k, generator=g) * scale).to(dev)
+    b = torch.randn(B, k, n, generator=g).to(dev)
+    bp = torch.empty(lib.runet_gemm_x3_pack_elems(B, k, n), device=dev, dtype=torch.bfloat16)
+    check(lib.runet_gemm_x3_pack(b.data_ptr(), k * n, bp.data_ptr(), B, k, n, st))
+    c = torch.full((B, rows, n + 4), 7.0, device=dev)          # row stride > n: the columns beyond n must stay untouched
+    check(lib.runet_gemm_x3_batched(a.data_ptr(), k, rows * k, bp.data_ptr(), c.data_ptr(), n + 4, rows * (n + 4), B, rows, k, n, st))
+    ref = torch.bmm(a.double().cpu(), b.double().cpu())
+    err = float((c[..., :n].double().cpu() - ref).abs().max() / ref.abs().max())
+    assert err <= 4e-6, err
+    assert float(c[..., n:].min()) == 7.0 and float(c[..., n:].max()) == 7.0
+    if rows % 16 == 0:
+        z = torch.randn(B, rows, n, generator=g).to(dev)
+        rps = max(16, (rows // 3 + 15) // 16 * 16)
+        splits = -(-rows // rps)
+        cu = torch.empty(splits, B, k, n, device=dev)
+        check(lib.runet_gemm_x3_tn_batched(a.data_ptr(), k, rows * k, z.data_ptr(), n, rows * n, cu.data_ptr(), B, rows, k, n, rps, st))
+        ref2 = torch.bmm(a.double().cpu().transpose(1, 2), z.double().cpu())
+        err2 = float((cu.double().sum(0).cpu() - ref2).abs().max() / ref2.abs().max())
+        assert err2 <= 4e-6, err2
+
+
+@pytest.mark.parametrize("n,h,w,ci,co", [(2, 16, 16, 64, 32), (1, 6, 10, 128, 384), (3, 8, 8, 16, 4), (2, 32, 32, 256, 128), (1, 4, 4, 1024, 512),
+                                         (2, 12, 20, 48, 36)])
+def test_conv_x3_matches_torch(n, h, w, ci, co, monkeypatch):
+    """csrc/conv_x3.hip: 1x1 convolution and k2-s2 transposed convolution, forward and data gradient, on the split-operand path against
+    float64 torch CPU ops (2e-5 of the result's scale: fp32-accurate), with bias, accumulate, channel-slice sources and destinations."""
+    ops = _ops()
+    monkeypatch.setattr(ops, "CONV_X3_MIN_K", 16)
+    monkeypatch.setattr(ops, "CONV_X3_WIDE_N", 4)
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(n * 1000 + h + ci + co)
+    x = torch.randn(n, ci, h, w, generator=g, dtype=torch.float64, requires_grad=True)
+    w1 = (torch.randn(co, ci, 1, 1, generator=g, dtype=torch.float64) / ci ** 0.5).requires_grad_(True)
+    wt = (torch.randn(ci, co, 2, 2, generator=g, dtype=torch.float64) / ci ** 0.5).requires_grad_(True)
+    b = torch.randn(co, generator=g, dtype=torch.float64)
+    y1 = F.conv2d(x, w1, b)
+    dy1 = torch.randn(y1.shape, generator=g, dtype=torch.float64)
+    gx1, = torch.autograd.grad(y1, x, dy1)
+    yt = F.conv_transpose2d(x, wt, b, stride=2)
+    dyt = torch.randn(yt.shape, generator=g, dtype=torch.float64)
+    gxt, = torch.autograd.grad(yt, x, dyt)
+
+    def nhwc(t):
+        return t.detach().float().permute(0, 2, 3, 1).contiguous().to(dev)
+
+    def close(got, ref, msg, tol=2e-5):
+        ref = ref.detach()
+        err = float((got.permute(0, 3, 1, 2).double().cpu() - ref).abs().max() / ref.abs().max())
+        assert err <= tol, f"{msg}: {err:.3e}"
+
+    xd, w1d, wtd, bd = nhwc(x), w1.detach().float().permute(2, 3, 1, 0).contiguous().to(dev), wt.detach().float().permute(2, 3, 0, 1).contiguous().to(dev), b.float().to(dev)
+    seen = []
+    real = ops._conv_x3
+    monkeypatch.setattr(ops, "_conv_x3", lambda mode, *a: (seen.append(mode), real(mode, *a))[1])
+    close(ops.conv_fwd(xd, w1d, bd), y1, "1x1 forward")
+    # channel-slice source and destination (concat buffers), accumulate
+    big = torch.zeros(n, h, w, ci + 32, device=dev)
+    big[..., 16:16 + ci] = xd
+    outb = torch.full((n, h, w, co + 8), 2.0, device=dev)
+    ops.conv_fwd(big[..., 16:16 + ci], w1d, None, out=outb[..., 4:4 + co], accumulate=True)
+    close(outb[..., 4:4 + co], y1 - b.view(1, -1, 1, 1) + 2.0, "1x1 forward, slices, accumulate")
+    assert float(outb[..., :4].min()) == 2.0 and float(outb[..., 4 + co:].max()) == 2.0
+    close(ops.conv_dgrad(nhwc(dy1), w1d), gx1, "1x1 data gradient")
+    acc = torch.full((n, h, w, ci), -1.0, device=dev)
+    ops.conv_dgrad(nhwc(dy1), w1d, out=acc, accumulate=True)
+    close(acc, gx1 - 1.0, "1x1 data gradient, accumulate")
+    cat = torch.zeros(n, 2 * h, 2 * w, 2 * co, device=dev)
+    ops.convt_fwd(xd, wtd, bd, out=cat[..., co:])
+    close(cat[..., co:], yt, "transposed forward into the right half of a concat buffer")
+    assert float(cat[..., :co].abs().max()) == 0.0
+    close(ops.convt_dgrad(nhwc(dyt), wtd), gxt, "transposed data gradient")
+    dcat = torch.zeros(n, 2 * h, 2 * w, 2 * co, device=dev)
+    dcat[..., co:] = nhwc(dyt)
+    close(ops.convt_dgrad(dcat[..., co:], wtd), gxt, "transposed data gradient from a slice")
+    # every call whose contraction is a multiple of 16 channels took the split-operand kernel (data gradients contract over `co`)
+    want = [ops.CONV_FWD, ops.CONVT_FWD] + ([ops.CONV_DGRAD, ops.CONVT_DGRAD] if co % 16 == 0 else [])
+    assert sorted(set(seen)) == sorted(want), seen

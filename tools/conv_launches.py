@@ -96,6 +96,27 @@ def main():
         batch, rows, k, n = a[8:12]
         return f"{'gemm NN (F4)':>14s} {batch}x[{rows}x{k}][{k}x{n}]", 4.0 * 2.0 * batch * rows * k * n, 4.0 * batch * (rows * (k + n) + k * n)
 
+    def d_conv_x3(a):    # x ldx wpacked bias y ldy n h w cin cout mode acc stream
+        n, h, w, cin, cout, mode, acc = a[6:13]
+        taps = 4 if mode in (2, 3) else 1
+        fl = 2.0 * n * h * w * taps * cin * cout
+        opix = 4 * n * h * w if mode == 2 else n * h * w
+        ipix = 4 * n * h * w if mode == 3 else n * h * w
+        by = 4.0 * (ipix * cin + opix * cout * (2 if acc else 1)) + 6.0 * taps * cin * cout
+        return f"{MODES.get(mode, mode):>14s} {n}x{h}x{w} {cin:4d}->{cout:4d} x3 ld{a[1]}/{a[5]}{' +=' if acc else ''}", fl, by
+
+    def d_gemm_x3_tn(a):  # a lda sa b ldb sb c batch rows k n rps stream
+        batch, rows, k, n = a[7:11]
+        return f"{'gemm TN x3':>14s} {batch}x[{rows}x{k}]^T[{rows}x{n}]", 4.0 * 2.0 * batch * rows * k * n, 4.0 * batch * rows * (k + n)
+
+    def d_gemm_x3_nn(a):  # a lda sa packed c ldc sc batch rows k n stream
+        batch, rows, k, n = a[7:11]
+        return f"{'gemm NN x3':>14s} {batch}x[{rows}x{k}][{k}x{n}]", 4.0 * 2.0 * batch * rows * k * n, 4.0 * batch * (rows * (k + n)) + 6.0 * batch * k * n
+
+    wrap("runet_conv_x3", d_conv_x3)
+    wrap("runet_wino4_conv_x3", d_wino4)
+    wrap("runet_gemm_x3_tn_batched", d_gemm_x3_tn)
+    wrap("runet_gemm_x3_batched", d_gemm_x3_nn)
     wrap("runet_gemm_tn_batched", d_gemm_tn)
     wrap("runet_gemm_batched", d_gemm_nn)
     wrap("runet_stem_conv", d_stem)
