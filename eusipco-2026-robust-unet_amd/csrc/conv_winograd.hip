@@ -580,7 +580,7 @@ struct WinoWgradDirectArgs {
 };
 
 // PH: position half (rows 2*PH, 2*PH + 1 of the position grid).  CABL: compile-time timing ablations (4: no loads, 8: no MFMA).
-template <int PH, int CABL>
+template <int PH, int CABL, bool ZIG = (CABL & 16) != 0>
 __device__ __forceinline__ void wino_wgrad_direct_body(const WinoWgradDirectArgs& g, int bsplit, int bchunk, int sub, int lane) {
     const int li = lane & 31, lh = lane >> 5;
     const int wco = 4 / g.wci;
@@ -607,9 +607,23 @@ __device__ __forceinline__ void wino_wgrad_direct_body(const WinoWgradDirectArgs
     unsigned offx, offy;                                // byte offsets of pixel (2ty, 2tx) (= patch element (1,1) = dy tile origin) + channel
     {
         const long tt = tg < g.tiles ? (long)tg : g.tiles - 1;
-        const int tn = (int)(tt / per);
-        const int rem = (int)(tt - (long)tn * per);
-        tty = rem / g.TX; ttx = rem - tty * g.TX;
+        int tn;
+        if constexpr (ZIG) {
+            // zig-zag order (see load()): position t' -> pair u = t' / 2 (two horizontally adjacent tiles, one per lane half), u even: upper
+            // tile row of a row pair, u odd: lower; v = u / 2 = (global row pair, column pair).  t_begin is a multiple of 4: u even here.
+            const long v = tt >> 2;
+            const int half = g.TX >> 1;
+            const long rp = v / half;
+            const int cp = (int)(v - rp * half);
+            const long grow = 2 * rp + ((tt >> 1) & 1);             // global tile row (image * TY + tile row)
+            tn = (int)(grow / g.TY);
+            tty = (int)(grow - (long)tn * g.TY);
+            ttx = 2 * cp + (int)(tt & 1);
+        } else {
+            tn = (int)(tt / per);
+            const int rem = (int)(tt - (long)tn * per);
+            tty = rem / g.TX; ttx = rem - tty * g.TX;
+        }
         offx = (unsigned)((((long)tn * g.H + 2 * tty) * g.W + 2 * ttx) * g.ldx + ca) * 4u;             // patch element (1, 1): always inside the image
         offy = (unsigned)((((long)tn * g.H + 2 * tty) * g.W + 2 * ttx) * g.ldy + cb) * 4u;
     }
@@ -619,7 +633,7 @@ __device__ __forceinline__ void wino_wgrad_direct_body(const WinoWgradDirectArgs
     // All constant parts of an address (patch row a, patch column b, dy tile element) ride in the buffer load's SCALAR offset: the vector
     // offset of every load of a stage is the patch origin itself or BIG.  fp32 MFMAs and VALU instructions compete for the same
     // SIMD cycles (a step costs matrix time PLUS 4 cycles per VALU instruction, measured), so every v_add removed here is matrix time.
-    auto load = [&](float (&rx)[12], float (&ry)[4]) {
+    auto load = [&](float (&rx)[12], float (&ry)[4], const int par) {
         const bool tv = tg < t_end_i;
         const unsigned ox = (tv && ca_ok && !(g.abl & 1)) ? offx : BIG, oy = (tv && cb_ok && !(g.abl & 2)) ? offy : BIG;
         // Patch rows PH, PH+1, PH+2 (patch row 1 = pixel row 2ty): the first (PH = 0) or the last (PH = 1) of them may lie outside the
@@ -653,13 +667,33 @@ __device__ __forceinline__ void wino_wgrad_direct_body(const WinoWgradDirectArgs
         }
         // advance by two tiles (TX >= 2: at most one wrap); branch-free, the loop body stays one basic block
         tg += 2;
-        ttx += 2;
-        const bool wx = ttx >= g.TX;
-        ttx -= wx ? g.TX : 0;
-        tty += wx ? 1 : 0;
-        tty = tty >= g.TY ? 0 : tty;
-        offx += 4 * ldx4 + (wx ? rowx4 : 0u);
-        offy += 4 * ldy4 + (wx ? rowy4 : 0u);
+        if constexpr (ZIG) {
+            // ZIG-ZAG over pairs of tile rows: (ty, tx..tx+1) -> (ty + 1, tx..tx+1) -> (ty, tx+2..tx+3) -> ...  Tile rows ty and ty + 1 share two
+            // of their four patch rows: in row-major order the second use came TX tiles later, after the XCD's L2 had turned over (PMC: 2.0x
+            // the algorithmic bytes); here it is the wave's next step.  `par` (the step's parity, a compile-time constant at every call
+            // site: the stage loop is unrolled six-fold and a tile range starts on an even step) says which move follows this load.
+            if (par == 0) {
+                tty += 1;
+                offx += 2 * rowx4;
+                offy += 2 * rowy4;
+            } else {
+                ttx += 2;
+                const bool wx = ttx >= g.TX;                        // end of the row pair: on to the next one (4 pixels right of the last column = one row down)
+                ttx -= wx ? g.TX : 0;
+                tty += wx ? 1 : -1;
+                tty = tty >= g.TY ? 0 : tty;
+                offx += 4 * ldx4 + (wx ? rowx4 : 0u - 2 * rowx4);
+                offy += 4 * ldy4 + (wx ? rowy4 : 0u - 2 * rowy4);
+            }
+        } else {
+            ttx += 2;
+            const bool wx = ttx >= g.TX;
+            ttx -= wx ? g.TX : 0;
+            tty += wx ? 1 : 0;
+            tty = tty >= g.TY ? 0 : tty;
+            offx += 4 * ldx4 + (wx ? rowx4 : 0u);
+            offy += 4 * ldy4 + (wx ? rowy4 : 0u);
+        }
     };
     // B^T d B rows {2PH, 2PH+1}: column pass over the three loaded rows, then the row pass;  A dY A^T rows likewise
     auto transform = [&](const float (&r)[12], const float (&cy)[4], float (&v)[8], float (&z)[8]) {
@@ -688,7 +722,7 @@ __device__ __forceinline__ void wino_wgrad_direct_body(const WinoWgradDirectArgs
     // one stage: multiply step s (operands op[s & 1]) | transform step s + 1 | load step s + 3
     auto stage = [&](int cur) {
         transform(raw_x[(cur + 1) % 3], raw_y[(cur + 1) % 3], op_v[(cur + 1) & 1], op_z[(cur + 1) & 1]);
-        load(raw_x[cur % 3], raw_y[cur % 3]);
+        load(raw_x[cur % 3], raw_y[cur % 3], (cur + 1) & 1);
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
             if constexpr (CABL & 8) acc[p][0] += op_v[cur & 1][p] * op_z[cur & 1][p];      // timing ablation: no MFMA
@@ -697,9 +731,9 @@ __device__ __forceinline__ void wino_wgrad_direct_body(const WinoWgradDirectArgs
         __builtin_amdgcn_sched_barrier(0);
     };
 
-    load(raw_x[0], raw_y[0]);                           // past the end of the range: out-of-range offsets, zero values
-    load(raw_x[1], raw_y[1]);
-    load(raw_x[2], raw_y[2]);
+    load(raw_x[0], raw_y[0], 0);                        // past the end of the range: out-of-range offsets, zero values
+    load(raw_x[1], raw_y[1], 1);
+    load(raw_x[2], raw_y[2], 0);
     transform(raw_x[0], raw_y[0], op_v[0], op_z[0]);
     __builtin_amdgcn_sched_barrier(0);
     for (long tb = t_begin; tb < t_end; tb += 12) {     // six stages of two tiles (lcm of the two ring lengths); stages past t_end multiply zeros
@@ -792,6 +826,10 @@ static bool wino_wgrad_direct(int n_img, int h, int w, long ldx, long ldy) {
     const long px = (long)n_img * h * w;
     return !lds_form && w >= 4 && px * ldx * 4 < (1L << 31) && px * ldy * 4 < (1L << 31) && px / 4 + 64 < (1L << 31);
 }
+static bool wino_wgrad_rowmajor() {      // measurement knob: RUNET_WINO_WGRAD_ROWMAJOR=1 -> the row-major tile order of round 2
+    static const bool v = getenv("RUNET_WINO_WGRAD_ROWMAJOR") && atoi(getenv("RUNET_WINO_WGRAD_ROWMAJOR")) != 0;
+    return v;
+}
 static WinoWgradPlan wino_wgrad_plan(int n_img, int h, int w, int cin, int cout, bool direct) {
     WinoWgradPlan p{};
     if (direct) {
@@ -803,7 +841,7 @@ static WinoWgradPlan wino_wgrad_plan(int n_img, int h, int w, int cin, int cout,
         const long maxs = cdiv(p.tiles, 64);
         if (splits > maxs) splits = maxs;
         if (splits < 1) splits = 1;
-        p.tps = cdiv(cdiv(p.tiles, splits), 2) * 2L;
+        p.tps = cdiv(cdiv(p.tiles, splits), 4) * 4L;     // multiple of 4: a tile range starts on an even step of the zig-zag order
         p.splits = cdiv(p.tiles, p.tps);
         return p;
     }
@@ -892,6 +930,7 @@ extern "C" int runet_wino_wgrad(const float* x, int ldx, const float* dy, int ld
         d.nsplits = p.splits; d.tiles = p.tiles; d.tiles_per_split = p.tps;
         if (abl & 4) hipLaunchKernelGGL(wino_wgrad_direct_kernel<4>, dim3(d.nchunks * p.splits), dim3(512), 0, st, d);
         else if (abl & 8) hipLaunchKernelGGL(wino_wgrad_direct_kernel<8>, dim3(d.nchunks * p.splits), dim3(512), 0, st, d);
+        else if ((h / 2) % 2 == 0 && !wino_wgrad_rowmajor()) hipLaunchKernelGGL(wino_wgrad_direct_kernel<16>, dim3(d.nchunks * p.splits), dim3(512), 0, st, d);   // zig-zag tile order
         else hipLaunchKernelGGL(wino_wgrad_direct_kernel<0>, dim3(d.nchunks * p.splits), dim3(512), 0, st, d);
     } else {
         hipLaunchKernelGGL(wino_wgrad_kernel, dim3(a.nchunks * p.splits), dim3(256), 0, st, a);

@@ -173,6 +173,67 @@ __global__ __launch_bounds__(256) void wino4_weight_kernel(const float* __restri
     }
 }
 
+// The same filter transform written STRAIGHT into the split-plane packing the bf16 matrix-core position GEMMs read (gemm_split.hip:
+// Up[36][plane 3][K/8][N][8] bf16, x = h + m + l exactly): one pass instead of wino4_weight_kernel + x3_pack_kernel - the fp32 U (4x the
+// weights) is never written or read (2 x 28 launches and 4.6 GB of the step's 105 GB were this round trip).  thread = (k octet, n), n fastest.
+typedef __bf16 w4_bf16x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void wino4_weight_x3_kernel(const float* __restrict__ w, __bf16* __restrict__ Up, int cin, int cout, int dgrad) {
+    const int K = dgrad ? cout : cin, N = dgrad ? cin : cout;
+    const int K8 = K >> 3;
+    const long per = (long)K8 * N;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= per) return;
+    const int oc = (int)(i / N), n = (int)(i - (long)oc * N);
+    float gm[8][3][3];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = oc * 8 + j;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                gm[j][r][q] = dgrad ? w[((long)((2 - r) * 3 + (2 - q)) * cin + n) * cout + k] : w[((long)(r * 3 + q) * cin + k) * cout + n];
+    }
+    auto grow = [](const float g0, const float g1, const float g2, const int a) -> float {      // row a of G applied to (g0, g1, g2)
+        const float e = (g0 + g2) * (1.f / 6.f), f = g0 * (1.f / 24.f) + g2 * (1.f / 6.f);
+        switch (a) {
+        case 0: return 0.25f * g0;
+        case 1: return -e - g1 * (1.f / 6.f);
+        case 2: return -e + g1 * (1.f / 6.f);
+        case 3: return f + g1 * (1.f / 12.f);
+        case 4: return f - g1 * (1.f / 12.f);
+        default: return g2;
+        }
+    };
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+        float u[6][8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float t0 = grow(gm[j][0][0], gm[j][1][0], gm[j][2][0], a), t1 = grow(gm[j][0][1], gm[j][1][1], gm[j][2][1], a),
+                        t2 = grow(gm[j][0][2], gm[j][1][2], gm[j][2][2], a);
+#pragma unroll
+            for (int b = 0; b < 6; ++b) u[b][j] = grow(t0, t1, t2, b);
+        }
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            w4_bf16x8 h, m, l;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float x = u[b][j];
+                const __bf16 hj = (__bf16)x;
+                const float r1 = x - (float)hj;
+                const __bf16 mj = (__bf16)r1;
+                h[j] = hj; m[j] = mj; l[j] = (__bf16)(r1 - (float)mj);
+            }
+            __bf16* d = Up + (long)(a * 6 + b) * 3 * per * 8 + i * 8;
+            *reinterpret_cast<w4_bf16x8*>(d) = h;
+            *reinterpret_cast<w4_bf16x8*>(d + per * 8) = m;
+            *reinterpret_cast<w4_bf16x8*>(d + 2 * per * 8) = l;
+        }
+    }
+}
+
 // dw[r][s][k][n] = (G^T (sum_splits dU[split][36][k][n]) G)[r][s]
 __device__ __forceinline__ void gt3(const float m0, const float m1, const float m2, const float m3, const float m4, const float m5, float (&r)[3]) {
     const float p = m1 + m2, q = m3 + m4;
@@ -239,6 +300,14 @@ extern "C" long runet_wino4_workspace_floats(int n_img, int h, int w, int k, int
 extern "C" int runet_wino4_weights(const float* w_hwio, float* U, int cin, int cout, int dgrad, void* stream) {
     RUNET_REQUIRE(w_hwio && U && cin > 0 && cout > 0, "bad arguments");
     hipLaunchKernelGGL(wino4_weight_kernel, dim3(cdiv((long)cin * cout, 256)), dim3(256), 0, (hipStream_t)stream, w_hwio, U, cin, cout, dgrad);
+    RUNET_CHECK_LAUNCH();
+}
+
+extern "C" int runet_wino4_weights_x3(const float* w_hwio, void* Upacked, int cin, int cout, int dgrad, void* stream) {
+    const int k = dgrad ? cout : cin, n = dgrad ? cin : cout;
+    RUNET_REQUIRE(w_hwio && Upacked && cin > 0 && cout > 0 && k % 8 == 0, "bad arguments (the contraction side must be a multiple of 8 channels)");
+    RUNET_REQUIRE(((uintptr_t)Upacked % 16) == 0, "alignment");
+    hipLaunchKernelGGL(wino4_weight_x3_kernel, dim3(cdiv((long)(k / 8) * n, 256)), dim3(256), 0, (hipStream_t)stream, w_hwio, (__bf16*)Upacked, cin, cout, dgrad);
     RUNET_CHECK_LAUNCH();
 }
 

@@ -914,10 +914,8 @@ def wino4_weights(w_hwio, dgrad=False):
     wp, dev = w_hwio.data_ptr(), w_hwio.device
     if _x3_case(k):
         def make_x3(out):
-            U = grow(_ws4, (dev.index, "U", stream()), 36 * k * n, dev, 1)
-            check(lib.runet_wino4_weights(wp, U.data_ptr(), cin, cout, int(dgrad), stream()))
             Up = out if out is not None else torch.empty(lib.runet_gemm_x3_pack_elems(36, k, n), device=dev, dtype=torch.bfloat16)
-            check(lib.runet_gemm_x3_pack(U.data_ptr(), k * n, Up.data_ptr(), 36, k, n, stream()))
+            check(lib.runet_wino4_weights_x3(wp, Up.data_ptr(), cin, cout, int(dgrad), stream()))      # transform + split in one pass
             Up.kn = (k, n)
             return Up
         return _cached(w_hwio, "wino4xd" if dgrad else "wino4x", make_x3)

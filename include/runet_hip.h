@@ -252,6 +252,9 @@ long runet_wino4_workspace_floats(int n_img, int h, int w, int k, int n);
 int runet_wino4_weights(const float* w_hwio, float* U, int cin, int cout, int dgrad, void* stream);
 int runet_wino4_conv(const float* x, int ldx, const float* U, const float* bias, float* y, int ldy, int n_img, int h, int w, int k, int n,
                      int dil, int accumulate, float* workspace, long workspace_floats, void* stream);
+/* runet_wino4_weights + runet_gemm_x3_pack in one pass: the filter transform written straight into the split planes (36 matrices [k][n] ->
+ * [36][3][k/8][n][8] bf16, runet_gemm_x3_pack_elems(36, k, n) elements); k (cin, or cout when dgrad != 0) a multiple of 8 */
+int runet_wino4_weights_x3(const float* w_hwio, void* Upacked, int cin, int cout, int dgrad, void* stream);
 /* runet_wino4_conv with the position-GEMMs on the bf16 matrix cores (split operands, fp32-accurate): Upacked = runet_gemm_x3_pack of U; k % 16 == 0 */
 int runet_wino4_conv_x3(const float* x, int ldx, const void* Upacked, const float* bias, float* y, int ldy, int n_img, int h, int w, int k, int n,
                         int dil, int accumulate, float* workspace, long workspace_floats, void* stream);
