@@ -46,7 +46,14 @@ sys.path.insert(0, ROOT)
 PKG = "eusipco-2026-robust-unet_amd"
 PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "fp16": 2500.0}   # MI355X_MICROARCH.md: dense matrix peaks (v_mfma_f32_32x32x2_f32 / v_mfma_f32_32x32x16_bf16)
 HBM_PEAK_GBS = 8000.0                          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured with a float4 copy)
-TRAFFIC_FILE = {"f32": "profiles/round2_pmc_traffic.json", "bf16": "profiles/round2_bf16_pmc_traffic.json", "fp16": "profiles/round2_fp16_pmc_traffic.json"}
+
+
+def traffic_file(model, dtype, batch, size):
+    """Committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE) of THIS workload, or None: the file is keyed by model, operand type and
+    per-GPU batch shape, so a line never quotes another configuration's bytes (tools/collect_profiles.sh writes them)."""
+    name = f"profiles/round3_pmc_traffic_{model}_{dtype}_{batch}x{size}.json"
+    return name if os.path.exists(os.path.join(ROOT, name)) else None
+
 
 CONFIGS = {   # BASELINE.json `configs`, per-GPU shard
     1: dict(model="runet", batch=2, size=64, dtype="f32"),
@@ -339,14 +346,15 @@ def run_rank(args):
         out.update(extra)
         if roof is not None:
             dom = roof["by_kernel"][roof["kernel"]]        # [launches, ms, algorithmic TFLOP/s, executed TFLOP/s]
-            traffic, hbm, src = None, None, TRAFFIC_FILE[args.dtype]
-            try:   # HBM bytes from the committed PMC passes
-                with open(os.path.join(ROOT, src)) as f:
-                    pmc = json.load(f)
-                for kname, rec in pmc["kernels"].items():      # rocprof prints template arguments, the live name may not
-                    if kname == roof["kernel"] or kname.startswith(roof["kernel"] + "<"):
-                        traffic = rec.get("hbm_bytes_per_launch_corrected")
-                hbm = pmc.get("step")
+            traffic, hbm, src = None, None, traffic_file(args.model, args.dtype, args.batch, args.size)
+            try:   # HBM bytes from the committed PMC passes of this workload
+                if src is not None:
+                    with open(os.path.join(ROOT, src)) as f:
+                        pmc = json.load(f)
+                    for kname, rec in pmc["kernels"].items():      # rocprof prints template arguments, the live name may not
+                        if kname == roof["kernel"] or kname.startswith(roof["kernel"] + "<"):
+                            traffic = rec.get("hbm_bytes_per_launch_corrected")
+                    hbm = pmc.get("step")
             except (OSError, ValueError, KeyError):
                 src = None
             exec_frac = dom[3] / peak

@@ -432,46 +432,65 @@ __global__ __launch_bounds__(TPB) void head3x3_fwd_kernel(const float* __restric
     }
 }
 // dl = dprob*p*(1-p);  dx[p][c] = sum_tap dl[p - tap] * w[tap][c];  partial dw[tap][c] = sum_p x[p+tap][c]*dl[p], db = sum dl
+// The weight / bias sums are reduced in a FIXED order (butterfly over the wave, one private LDS row per wave, rows added in wave order,
+// blocks summed by sum_rows_kernel): an earlier version used LDS float atomics and two runs of the same step differed in the last bit of
+// decoder.12.weight (found by tests/test_gpu_deeplab.py::test_deeplab_at_the_benchmarked_size).
 __global__ __launch_bounds__(TPB) void head3x3_bwd_kernel(const float* __restrict__ dprob, const float* __restrict__ prob,
                                                           const float* __restrict__ x, int ld, const float* __restrict__ w,
                                                           float* __restrict__ dx, int lddx, float* __restrict__ part, int N, int H, int W, int C) {
     extern __shared__ float sm[];
+    constexpr int NW = TPB / 64;
+    const int R = 9 * C + 1;
     float* ws = sm;                    // [9*C]
-    float* red = sm + 9 * C;           // [9*C + 1] block partial
+    float* red = sm + 9 * C;           // [NW][9*C + 1] per-wave partials
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < 9 * C; i += TPB) ws[i] = w[i];
-    for (int i = threadIdx.x; i < 9 * C + 1; i += TPB) red[i] = 0.f;
+    for (int i = threadIdx.x; i < NW * R; i += TPB) red[i] = 0.f;
     __syncthreads();
+    float* mine = red + wave * R;
     const long total = (long)N * H * W;
-    for (long p = (long)blockIdx.x * TPB + threadIdx.x; p < total; p += (long)gridDim.x * TPB) {
-        const int wq = (int)(p % W);
-        const long t = p / W;
+    for (long base = (long)blockIdx.x * TPB; base < total; base += (long)gridDim.x * TPB) {      // uniform trip count: every lane joins the wave sums
+        const long p = base + threadIdx.x;
+        const bool valid = p < total;
+        const long pc = valid ? p : total - 1;
+        const int wq = (int)(pc % W);
+        const long t = pc / W;
         const int h = (int)(t % H);
         const long n = t / H;
-        const float pr = prob[p];
-        const float dl = dprob[p] * pr * (1.f - pr);
-        atomicAdd(&red[9 * C], dl);
-        for (int c = 0; c < C; ++c) {
-            float g = 0.f;
-            for (int k = 0; k < 9; ++k) {
-                const int oh = h + 1 - k / 3, ow = wq + 1 - k % 3;      // output pixel whose tap k reads this input pixel
-                if ((unsigned)oh < (unsigned)H && (unsigned)ow < (unsigned)W) {
-                    const long q = (n * H + oh) * W + ow;
-                    const float pq = prob[q];
-                    g += dprob[q] * pq * (1.f - pq) * ws[k * C + c];
+        const float pr = prob[pc];
+        const float dl = valid ? dprob[pc] * pr * (1.f - pr) : 0.f;
+        const float sdl = wave_sum(dl);
+        if (lane == 0) mine[9 * C] += sdl;
+        if (valid) {
+            for (int c = 0; c < C; ++c) {
+                float g = 0.f;
+                for (int k = 0; k < 9; ++k) {
+                    const int oh = h + 1 - k / 3, ow = wq + 1 - k % 3;      // output pixel whose tap k reads this input pixel
+                    if ((unsigned)oh < (unsigned)H && (unsigned)ow < (unsigned)W) {
+                        const long q = (n * H + oh) * W + ow;
+                        const float pq = prob[q];
+                        g += dprob[q] * pq * (1.f - pq) * ws[k * C + c];
+                    }
                 }
+                dx[p * lddx + c] = g;
             }
-            dx[p * lddx + c] = g;
         }
         for (int k = 0; k < 9; ++k) {
             const int ih = h - 1 + k / 3, iw = wq - 1 + k % 3;
-            if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
-                const float* xp = x + ((n * H + ih) * W + iw) * ld;
-                for (int c = 0; c < C; ++c) atomicAdd(&red[k * C + c], xp[c] * dl);
+            const bool in = valid && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+            const float* xp = x + ((n * H + (in ? ih : h)) * W + (in ? iw : wq)) * ld;
+            for (int c = 0; c < C; ++c) {
+                const float s = wave_sum(in ? xp[c] * dl : 0.f);
+                if (lane == 0) mine[k * C + c] += s;
             }
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 9 * C + 1; i += TPB) part[(long)blockIdx.x * (9 * C + 1) + i] = red[i];
+    for (int i = threadIdx.x; i < R; i += TPB) {
+        float a = red[i];
+        for (int v = 1; v < NW; ++v) a += red[v * R + i];
+        part[(long)blockIdx.x * R + i] = a;
+    }
 }
 __global__ void sum_rows_kernel(const float* __restrict__ part, int nrows, int ncols, float* __restrict__ out) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -512,7 +531,7 @@ extern "C" int runet_head3x3_bwd(const float* dprob, const float* prob, const fl
     hipStream_t st = (hipStream_t)stream;
     long blocks = ((long)n_img * h * w_ + TPB - 1) / TPB;
     if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(head3x3_bwd_kernel, dim3((int)blocks), dim3(TPB), (18 * c + 1) * sizeof(float), st, dprob, prob, x, ld, w, dx, lddx, workspace, n_img, h, w_, c);
+    hipLaunchKernelGGL(head3x3_bwd_kernel, dim3((int)blocks), dim3(TPB), (9 * c + (TPB / 64) * (9 * c + 1)) * sizeof(float), st, dprob, prob, x, ld, w, dx, lddx, workspace, n_img, h, w_, c);
     hipLaunchKernelGGL(sum_rows_kernel, dim3(cdiv(9 * c + 1, 128)), dim3(128), 0, st, workspace, (int)blocks, 9 * c + 1, dw_db);
     RUNET_CHECK_LAUNCH();
 }

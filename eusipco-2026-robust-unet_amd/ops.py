@@ -317,13 +317,16 @@ USE_WINOGRAD4 = USE_WINOGRAD and os.environ.get("RUNET_NO_WINOGRAD4", "0") != "1
 USE_WINOGRAD4_DILATED = USE_WINOGRAD4 and os.environ.get("RUNET_NO_WINOGRAD4_DILATED", "0") != "1"
 
 
+WINO4_MIN_WIDE = int(os.environ.get("RUNET_WINO4_MIN_WIDE", "256"))      # channels the wider side needs for the unfused F(4x4) path
+
+
 def _wino4_case(h, w, kh, dil, k, n, cin_w):
     """Deep layers (>= 256 channels on one side, <= 128x128 pixels): unfused F(4x4,3x3) beats the fused F(2x2) kernel (tools/bench_conv.py).
     Dilated 3x3 convolutions (the bottleneck's DilatedBlock, dilation 2 and 4) take the same path as dil*dil dilation-1 convolutions over
     the sub-images of every image (csrc/conv_winograd4.hip pix()): 4x fewer multiplies than the implicit GEMM they used before."""
     if dil != 1 and not (USE_WINOGRAD4_DILATED and h % dil == 0 and w % dil == 0):
         return False
-    return (USE_WINOGRAD4 and kh == 3 and cin_w == k and max(k, n) >= 256 and min(k, n) >= 128 and h * w <= 128 * 128
+    return (USE_WINOGRAD4 and kh == 3 and cin_w == k and max(k, n) >= WINO4_MIN_WIDE and min(k, n) >= 128 and h * w <= 128 * 128
             and bool(lib.runet_wino4_supported(h // dil, w // dil, k, n)))
 
 

@@ -85,8 +85,8 @@ def aspp(P, x, training=True):
     return _bn_relu(P, "aspp.bn", _conv(P, "aspp.conv_out", torch.cat(branches, 1)), training)
 
 
-def forward(P, x, training=True, taps=None):
-    """P: state dict (tensors; parameters may require grad).  -> sigmoid probabilities [N,1,H,W]"""
+def forward(P, x, training=True, taps=None, return_logit=False):
+    """P: state dict (tensors; parameters may require grad).  -> sigmoid probabilities [N,1,H,W] (return_logit: (prob, logit), both attached)"""
     def tap(k, v):
         if taps is not None:
             taps[k] = v.detach().clone()
@@ -100,4 +100,5 @@ def forward(P, x, training=True, taps=None):
     for i in (0, 3, 6, 9):
         x = F.conv_transpose2d(x, P[f"decoder.{i}.weight"], P[f"decoder.{i}.bias"], stride=2, padding=1)
         x = tap(f"decoder.{i}", _bn_relu(P, f"decoder.{i + 1}", x, training))
-    return torch.sigmoid(tap("logit", _conv(P, "decoder.12", x, 1, 1)))
+    logit = tap("logit", _conv(P, "decoder.12", x, 1, 1))
+    return (torch.sigmoid(logit), logit) if return_logit else torch.sigmoid(logit)

@@ -70,3 +70,43 @@ def test_sigmoid_saturation_is_a_decision(pkg, oracle):
     g2, _, _, _ = D.oracle_step(oracle, st, masks, x, y, forced=D.forced_from_hip(dec, None))
     db = float((g2["outc.0.bias"] - g0["outc.0.bias"]).abs().max())
     assert abs(db - 1.0 / prob.numel()) <= 1e-3 / prob.numel(), db      # d loss / d logit of that pixel went from 0 to (1 - 2^-24) / n
+
+
+def test_sequential_recorder_forcing_own_decisions_is_the_identity(pkg):
+    """tests/decisions_seq.py (plain U-Net / DeepLabV3+): forcing the oracle's own ReLU masks and pool winners reproduces its gradients
+    bit for bit; a moved pool winner is listed with its margin and changes them."""
+    import importlib
+
+    import decisions_seq as DS
+    pu = importlib.import_module("oracle.plain_unet_ref")
+    st = pu.init_state(3, 2, seed=4, perturb_bn=True)
+    names = pu.param_names(3, 2)
+    x, y = pkg.synthetic_batch(2, 32, seed=4)
+    target = y[:, 0].long()
+
+    def run(forced):
+        P = {k: v.clone() for k, v in st.items()}
+        for k in names:
+            P[k].requires_grad_(True)
+
+        def step(rec):
+            logits = pu.forward(P, x, True)
+            return (lambda _: pu.ce_mean(logits, target)), None, None
+        log, _ = DS.run_oracle(pu, step, forced)
+        return log, {k: P[k].grad for k in names}
+
+    log, g0 = run(None)
+    assert [k for k, _, _ in log].count("pool") == 4 and [k for k, _, _ in log].count("relu") == 18
+    own = [d for _, d, _ in log]
+    assert DS.differing(own, log) == []
+    _, g1 = run(own)
+    assert max(float((g0[k] - g1[k]).abs().max()) for k in names) == 0.0
+    moved = [d.clone() for d in own]
+    i = [j for j, (k, _, _) in enumerate(log) if k == "pool"][0]
+    w_in = log[i][2].shape[3]
+    cur = int(moved[i][0, 0, 0, 0])
+    moved[i][0, 0, 0, 0] = cur + 1 if cur % w_in == 0 else cur - 1          # the other column of the same 2x2 window
+    flips = DS.differing(moved, log)
+    assert len(flips) == 1 and flips[0][1] == "pool" and flips[0][3] >= 0.0
+    _, g2 = run(moved)
+    assert max(float((g0[k] - g2[k]).abs().max()) for k in names) > 0.0

@@ -162,7 +162,8 @@ def test_deeplab_train_step_matches_reference(pkg, tag):
     for k, p in model.named_parameters():
         if k in zero_bias:
             continue
-        g = p.grad
+        g = p.grad      # 1e-2 band: the fixed golden file cannot follow a flipped near-tie decision; the tight check (5e-4 under the HIP step's own
+        # decisions) is test_deeplab_gradients_under_the_hip_decisions below
         if f"grad/{k}" in gold:
             gr = gold[f"grad/{k}"]
             np.testing.assert_allclose(g.cpu().numpy(), gr, rtol=1e-2, atol=1e-2 * float(np.abs(gr).max()) + 1e-9, err_msg=k)
@@ -219,3 +220,90 @@ def test_aspp_standalone_matches_the_oracle(pkg):
         if k.endswith(".bias") and k.startswith("conv") and float(ref.abs().max()) < 1e-4:
             continue            # conv biases in front of the train-mode BatchNorm: analytically zero gradient, rounding noise on both sides
         close(p.grad, ref, k, 2e-3)
+
+
+@pytest.mark.parametrize("n,size,seed", [(2, 64, 11), (2, 128, 12)])
+def test_deeplab_gradients_under_the_hip_decisions(pkg, n, size, seed, monkeypatch):
+    """Decision-aware gradient parity for the DeepLabV3+ baseline (tests/decisions_seq.py): ReLU masks, MaxPool2d(3, 2, 1) winners and sigmoid
+    saturation on which the HIP step and the oracle differ are near-ties; under the HIP step's own decisions every gradient element is within
+    5e-4 of its tensor's scale (the golden test above allows 1e-2: it cannot re-evaluate the reference under other decisions)."""
+    import decisions_seq as DS
+    dl = importlib.import_module("oracle.deeplab_ref")
+    dmod = importlib.import_module("eusipco-2026-robust-unet_amd.deeplab")
+    st = dl.init_state(seed=seed, perturb_bn=True)
+    model = pkg.DeepLabV3Plus(n_classes=1)
+    model.load_state_dict(st)
+    model = model.to(DEV).train()
+    x, y = pkg.synthetic_batch(n, size, seed=seed)
+    got = {}
+    real = dmod.dl_backward
+
+    def spy(net_, C, dprob):
+        def mask(t):
+            return (t.detach() > 0).permute(0, 3, 1, 2).cpu()
+        idx, h1, w1 = C["pool"]
+        dec = [mask(C["conv1"]["act"]), DS.pool_flat_3s2(idx.permute(0, 3, 1, 2).cpu().long(), w1)]
+        dec += [mask(C[k]["act"]) for k in ("conv2", "conv3", "conv4")]
+        dec.append(mask(C["aspp"]["aa"]))
+        dec += [mask(C[f"dec{i}"]["act"]) for i in range(4)]
+        got["dec"] = dec
+        return real(net_, C, dprob)
+
+    monkeypatch.setattr(dmod, "dl_backward", spy)
+    prob = model(x.to(DEV))
+    pkg.bce_loss(prob, y.to(DEV)).backward()
+    torch.cuda.synchronize()
+    hip_prob = prob.detach().cpu()
+    names = dl.param_names()
+
+    def oracle(forced, forced_prob):
+        P = {k: v.clone() for k, v in st.items()}
+        for k in names:
+            P[k].requires_grad_(True)
+
+        def step(rec):
+            p, logit = dl.forward(P, x, True, return_logit=True)
+            return (lambda pp: torch.nn.functional.binary_cross_entropy(pp, y)), p, logit
+        log, rp = DS.run_oracle(dl, step, forced, forced_prob)
+        return log, {k: P[k].grad for k in names}, rp
+
+    log, _, ref_prob = oracle(None, None)
+    np.testing.assert_allclose(hip_prob.numpy(), ref_prob.numpy(), rtol=0, atol=1e-3)
+    flips = DS.differing(got["dec"], log, hip_prob, ref_prob)
+    DS.assert_near_ties(flips)
+    _, gref, _ = oracle(got["dec"], hip_prob)
+    zero_bias = {"conv1.0.bias", "conv2.1.bias", "conv3.0.bias", "conv4.0.bias", "aspp.conv_out.bias", "decoder.0.bias", "decoder.3.bias",
+                 "decoder.6.bias", "decoder.9.bias"}
+    rows = DS.grad_errors({k: p.grad.detach().cpu() for k, p in model.named_parameters()}, gref, zero_bias)
+    print(f"\nDeepLabV3+ {n} x {size}^2: {len(flips)} near-tie decisions forced; worst gradient errors / scale {[(f'{e:.1e}', k) for e, k in rows[:4]]}, median {np.median([r[0] for r in rows]):.1e}")
+    assert rows[0][0] <= 5e-4, rows[:4]          # measured: 1.6e-4 at worst (a transposed convolution's bias: a sum over every pixel), 1e-5 typical
+    assert float(np.median([r[0] for r in rows])) <= 3e-5
+
+
+def test_deeplab_at_the_benchmarked_size(pkg):
+    """BASELINE config 4 at its own size (16 x 256^2): two train steps from the same state are bit-identical (no atomics, fixed-order
+    reductions), and the eval-mode batch equals the oracle evaluated on two of its images (running-statistics BatchNorm makes images
+    independent) - the full-batch oracle would take minutes on the host."""
+    dl = importlib.import_module("oracle.deeplab_ref")
+    st = dl.init_state(seed=21, perturb_bn=True)
+    x, y = pkg.synthetic_batch(16, 256, seed=21)
+    xd, yd = x.to(DEV), y.to(DEV)
+    grads = []
+    for _ in range(2):
+        model = pkg.DeepLabV3Plus(n_classes=1)
+        model.load_state_dict(st)
+        model = model.to(DEV).train()
+        prob = model(xd)
+        loss = pkg.bce_loss(prob, yd)
+        loss.backward()
+        grads.append((loss.item(), prob.detach().clone(), [p.grad.detach().clone() for p in model.parameters()]))
+    assert grads[0][0] == grads[1][0] and torch.equal(grads[0][1], grads[1][1])
+    assert all(torch.equal(a, b) for a, b in zip(grads[0][2], grads[1][2]))
+    model.eval()
+    with torch.no_grad():
+        pe = model(xd).cpu()
+        P = {k: v.clone() for k, v in model.state_dict().items()}
+        P = {k: v.cpu() for k, v in P.items()}
+        # the module keeps physical (permuted-stride) weights; .cpu() preserves logical shapes
+        ref = dl.forward(P, x[[3, 12]], False)
+    np.testing.assert_allclose(pe[[3, 12]].numpy(), ref.numpy(), rtol=0, atol=1e-3)

@@ -57,7 +57,8 @@ def test_plain_unet_train_step_matches_reference(pkg, tag):
         # every element within 3e-2 of the tensor's scale (1 % of them - at least one - up to 0.2: a flipped decision lands on one channel) and the RMS error within 1 % of that scale (scale = the tensor's largest magnitude, at least 1e-3 of the largest gradient anywhere: the
         # transposed convolutions' biases are sums that cancel to ~1e-3 of their terms): the deep levels of these 2-image
         # tiles normalise 8 .. 32 values per channel, and a ReLU / max-pool decision at a near-tie moves a few elements by ~1e-2
-        # (tests/decisions.py explains and, for the Robust U-Net, removes that lottery; measured here: worst element 5.5e-3)
+        # (tests/decisions.py explains that lottery; test_plain_unet_gradients_under_the_hip_decisions below removes it for this model and
+        # holds every element to 5e-4 - this fixed golden file cannot be re-evaluated under other decisions, so its band stays wide)
         scale = max(float(np.abs(b).max()), 1e-3 * gmax)          # tensors 1000x smaller than the largest gradient are rounding-level sums
         err = np.abs(a - b)
         assert err.max() <= 0.2 * scale and int((err > 3e-2 * scale).sum()) <= max(1, err.size // 100), (k, err.max(), scale)
@@ -113,3 +114,65 @@ def test_checkpoint_from_fit_loads_into_the_oracle_and_back(pkg, tmp_path):
         got = net(xs[:2].to(DEV)).cpu()
     want = pu.forward({k: v.clone() for k, v in ck.items()}, xs[:2], training=False)
     np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=0, atol=1e-3 * max(1.0, float(want.abs().max())))
+
+
+@pytest.mark.parametrize("n,size,seed", [(2, 64, 5), (2, 128, 6)])
+def test_plain_unet_gradients_under_the_hip_decisions(pkg, n, size, seed, monkeypatch):
+    """Decision-aware gradient parity (tests/decisions_seq.py), the check that replaced the loose golden bands for the Robust U-Net: ReLU
+    masks and 2x2 pool winners on which the HIP step and the oracle differ are near-ties, and under the HIP step's own decisions EVERY
+    gradient element is within 5e-4 of its tensor's scale (measured 1e-5 .. 1.6e-4; the golden test above has to allow 0.2 because a
+    flipped decision at these 8-32 values-per-channel depths moves single elements by ~1e-2)."""
+    import decisions_seq as DS
+    pu = _pu()
+    unet_mod = importlib.import_module("eusipco-2026-robust-unet_amd.unet")
+    st = pu.init_state(3, 2, seed=seed, perturb_bn=True)
+    net = pkg.UNet(3, 2)
+    net.load_state_dict(st)
+    net = net.to(DEV).train()
+    x, y = pkg.synthetic_batch(n, size, seed=seed)
+    target = y[:, 0].long()
+    got = {}
+    real = unet_mod.unet_backward
+
+    def spy(net_, C, dlogits):
+        def mask(t):
+            return (t.detach() > 0).permute(0, 3, 1, 2).cpu()
+        dec = []
+        a2 = {f"enc{l}": C[f"dec{l}"]["x"][..., unet_mod.CH[l - 1]:] for l in (1, 2, 3, 4)}
+        a2.update({"bottleneck": C["up4"][0], "dec4": C["up3"][0], "dec3": C["up2"][0], "dec2": C["up1"][0], "dec1": C["head"][0]})
+        for l in (1, 2, 3, 4):
+            dec += [mask(C[f"enc{l}"]["a1"]), mask(a2[f"enc{l}"])]
+            dec.append(DS.pool_flat_2x2(C[f"pool{l}"].permute(0, 3, 1, 2).cpu().long(), size >> (l - 1)))
+        for k in ("bottleneck", "dec4", "dec3", "dec2", "dec1"):
+            dec += [mask(C[k]["a1"]), mask(a2[k])]
+        got["dec"] = dec
+        return real(net_, C, dlogits)
+
+    monkeypatch.setattr(unet_mod, "unet_backward", spy)
+    logits = net(x.to(DEV))
+    pkg.cross_entropy(logits, target.to(DEV)).backward()
+    torch.cuda.synchronize()
+    names = [k for k in pu.param_names(3, 2)]
+
+    def oracle(forced):
+        P = {k: v.clone() for k, v in st.items()}
+        for k in names:
+            P[k].requires_grad_(True)
+        out = {}
+
+        def step(rec):
+            out["logits"] = pu.forward(P, x, True)
+            return (lambda _: pu.ce_mean(out["logits"], target)), None, None
+        log, _ = DS.run_oracle(pu, step, forced)
+        return log, {k: P[k].grad for k in names}, out["logits"].detach()
+
+    log, _, ref_logits = oracle(None)
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), ref_logits.numpy(), rtol=0, atol=1e-3 * max(1.0, float(ref_logits.abs().max())))
+    flips = DS.differing(got["dec"], log)
+    DS.assert_near_ties(flips)
+    _, gref, _ = oracle(got["dec"])
+    skip = {k for k in names if k.endswith(".bias") and k.split(".")[-2] in ("0", "3")}      # conv bias in front of a train-mode BatchNorm: analytically zero
+    rows = DS.grad_errors({k: p.grad.detach().cpu() for k, p in net.named_parameters()}, gref, skip)
+    print(f"\nplain U-Net {n} x {size}^2: {len(flips)} near-tie decisions forced; worst gradient errors / scale {[(f'{e:.1e}', k) for e, k in rows[:4]]}, median {np.median([r[0] for r in rows]):.1e}")
+    assert rows[0][0] <= 5e-4, rows[:4]          # measured: 1.6e-4 at worst (a transposed convolution's bias: a sum over every pixel), 1e-5 typical
+    assert float(np.median([r[0] for r in rows])) <= 3e-5

@@ -10,7 +10,7 @@ for C in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_I
          "SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_INSTS_SALU SQ_WAVES" \
          "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  rocprofv3 --pmc $C --output-format csv -d $ROOT/$OUT/p$i -- python3 $ROOT/tools/conv_one.py "$@" 2 > /dev/null 2>&1
+  rocprofv3 --pmc $C --output-format csv -d $ROOT/$OUT/p$i -- python3 $ROOT/tools/${PMC_SCRIPT:-conv_one.py} "$@" ${PMC_ITERS-2} > /dev/null 2>&1
 done
 cd $ROOT
 python3 - $OUT <<'PY'
