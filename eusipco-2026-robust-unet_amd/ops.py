@@ -419,11 +419,23 @@ def conv_fwd(x, w_hwio, bias=None, out=None, dil=1, accumulate=False, keep_v=Non
     return out
 
 
+# the fused F(2x2) kernel with its position products on the BF16 matrix cores (csrc/conv_winograd_x3.hip); RUNET_NO_WINO_X3=1: the f32-MFMA kernel
+USE_WINO_X3 = os.environ.get("RUNET_NO_WINO_X3", "0") != "1"
+
+
 def wino_weights(w_hwio, dgrad=False):
-    """HWIO 3x3 weight -> Winograd-domain U[16][K][N] (forward: K=cin, N=cout; dgrad: rotated filter, K=cout, N=cin)."""
+    """HWIO 3x3 weight -> Winograd-domain U[16][K][N] (forward: K=cin, N=cout; dgrad: rotated filter, K=cout, N=cin); under USE_X3 the
+    split-plane form Up[16][3][K/8][N][8] bf16 that runet_wino_conv_x3 reads."""
     _, _, cin, cout = w_hwio.shape
     k, n = (cout, cin) if dgrad else (cin, cout)
     wp, dev = w_hwio.data_ptr(), w_hwio.device
+    if USE_X3 and USE_WINO_X3 and k % 16 == 0:
+        def make_x3(out):
+            Up = out if out is not None else torch.empty(lib.runet_wino_x3_pack_elems(k, n), device=dev, dtype=torch.bfloat16)
+            check(lib.runet_wino_weights_x3(wp, Up.data_ptr(), cin, cout, int(dgrad), stream()))
+            Up.kn = (k, n)
+            return Up
+        return _cached(w_hwio, "wino2xd" if dgrad else "wino2x", make_x3)
 
     def make(out):
         U = out if out is not None else torch.empty((16, k, n), device=dev, dtype=torch.float32)
@@ -435,18 +447,20 @@ def wino_weights(w_hwio, dgrad=False):
 def wino_conv(x, U, bias=None, out=None, accumulate=False):
     """3x3 'same' convolution (or its data gradient, with dgrad weights) through the fused Winograd kernel."""
     n, h, w, k = x.shape
-    nn_ = U.shape[2]
+    x3 = U.dtype == torch.bfloat16                      # split-plane filter (wino_weights under USE_X3)
+    nn_ = U.kn[1] if x3 else U.shape[2]
     if out is None:
         out = empty_nhwc(n, h, w, nn_, x)
     if _PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(lib.runet_wino_conv(x.data_ptr(), ld(x), U.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(), ld(out),
-                              n, h, w, k, nn_, int(accumulate), stream()))
+    fn = lib.runet_wino_conv_x3 if x3 else lib.runet_wino_conv
+    check(fn(x.data_ptr(), ld(x), U.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(), ld(out),
+             n, h, w, k, nn_, int(accumulate), stream()))
     if _PROFILE is not None:
         e1.record()
         fl = 2.0 * n * h * w * 9 * k * nn_
-        _PROFILE.append(("wino_conv_kernel", fl, fl * 16.0 / 36.0, e0, e1))
+        _PROFILE.append(("wino_conv_x3_kernel" if x3 else "wino_conv_kernel", fl, fl * 16.0 / 36.0, e0, e1))
     return out
 
 

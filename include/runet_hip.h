@@ -76,6 +76,15 @@ int runet_wino_weights(const float* w_hwio, float* U, int cin, int cout, int dgr
 int runet_wino_conv(const float* x, int ldx, const float* U, const float* bias, float* y, int ldy, int n_img, int h, int w, int k, int n,
                     int accumulate, void* stream);
 
+/* The same convolution with its sixteen position products on the BF16 matrix cores (csrc/conv_winograd_x3.hip: split operands, six bf16
+ * MFMAs per fp32 product, fp32-accurate).  runet_wino_weights_x3 writes G g G^T straight into the split planes Up[16][3][K/8][N][8] bf16
+ * (runet_wino_x3_pack_elems(K, N) 2-byte elements, once per optimizer step); runet_wino_conv_x3 = runet_wino_conv on them (ldx % 4 == 0,
+ * x 16-byte aligned). */
+long runet_wino_x3_pack_elems(int k, int n);
+int runet_wino_weights_x3(const float* w_hwio, void* Upacked, int cin, int cout, int dgrad, void* stream);
+int runet_wino_conv_x3(const float* x, int ldx, const void* Upacked, const float* bias, float* y, int ldy, int n_img, int h, int w, int k, int n,
+                       int accumulate, void* stream);
+
 /* Winograd-domain weight gradient of the same convolutions: dw[3][3][cin][cout] = G^T [sum_tiles (B^T x B).*(A dy A^T)] G.
  * workspace: >= runet_wino_wgrad_workspace_floats floats (partial slabs, summed in a fixed order).  H, W even. */
 long runet_wino_wgrad_workspace_floats(int n_img, int h, int w, int cin, int cout);

@@ -124,6 +124,7 @@ def main():
     wrap("runet_conv_igemm", d_igemm)
     wrap("runet_conv_wgrad", d_wgrad)
     wrap("runet_wino_conv", d_wino)
+    wrap("runet_wino_conv_x3", d_wino)
     wrap("runet_wino_wgrad", d_wino_wgrad)
     wrap("runet_wino4_conv", d_wino4)
     wrap("runet_wino4_wgrad", d_wino4_wgrad)
