@@ -18,7 +18,8 @@ bf16; 4: DeepLabV3+ 16x256x256; 5: 1x1024x1024 per GPU, fp16 operands + loss sca
 
 Extra objects on the line:
   roofline     - the dominant matrix-core kernel of the step (largest accumulated launch time).  `frac` = EXECUTED multiply-add FLOPs
-                 per launch / average launch duration / dense MFMA peak of the operand type (fp32 157.3 TFLOP/s; bf16 2500), the
+                 per launch / average launch duration / dense MFMA peak of the arithmetic's type (fp32 157.3 TFLOP/s; bf16 2500; the
+                 split-operand "x3" kernels do fp32 arithmetic with six bf16 MFMAs per product: `bf16_matrix_pipe` has that view), the
                  duration measured with HIP events on the launch stream inside the timed steps.  Winograd kernels execute 16/36
                  (F(2x2)) or 36/144 (F(4x4)) of the direct convolution's multiplies: `algorithmic` is the direct-conv rate (SURVEY
                  section 8d), `frac` the matrix-pipe utilisation of the work actually issued.  `step_mfma_frac` = executed FLOPs of
@@ -373,6 +374,14 @@ def run_rank(args):
                                        "F(4x4) position-GEMMs: 36/144 of the direct convolution) / HIP-event launch time; algorithmic = direct-conv FLOPs / the same time",
                                "concurrency": "weight-gradient kernels run on a second HIP stream during backward: launch durations (live events and rocprofv3 "
                                               "alike) include time shared with them; `standalone` repeats the measurement single-stream after the timed region"}
+            if "x3" in roof["kernel"]:
+                # split-operand kernels: the fp32 multiply-adds above are issued as six bf16 MFMAs each (x = h + m + l, six of nine cross
+                # products) - the occupancy of the pipe they actually run on is 6 x that rate against the dense bf16 peak
+                out["roofline"]["bf16_matrix_pipe"] = {"achieved": round(6.0 * dom[3], 1), "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s",
+                                                       "frac": round(6.0 * dom[3] / PEAK_TFLOPS["bf16"], 4),
+                                                       "note": "fp32-accurate arithmetic on the bf16 matrix cores: `achieved` / `frac` above count the fp32 "
+                                                               "multiply-adds against the fp32 MFMA peak (the arithmetic's own roofline), this block counts "
+                                                               "the bf16 MFMAs issued (6 per fp32 product) against the dense bf16 peak"}
             if hbm is not None:
                 out["roofline"]["hbm"] = hbm
             if alone is not None:      # [launches, total ms, algorithmic, executed] of the same kernel in three single-stream steps after the timed region

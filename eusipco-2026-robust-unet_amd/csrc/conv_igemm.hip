@@ -973,7 +973,10 @@ static bool wgrad1x1_direct(long P, int cin, int cout) {
     static const bool direct = getenv("RUNET_GEMM_TN_DIRECT") && atoi(getenv("RUNET_GEMM_TN_DIRECT")) != 0;
     if (off || P * 4 >= (1L << 31)) return false;
     if (direct) return !((long)cin * cout <= 8192 && P >= (1L << 19));
-    return cin >= 128 && cout >= 128;
+    // RUNET_WGRAD1X1_MIN_NARROW (measurement knob, default 128): channels the NARROWER side needs (the wider one always >= 128)
+    static const int narrow = getenv("RUNET_WGRAD1X1_MIN_NARROW") ? atoi(getenv("RUNET_WGRAD1X1_MIN_NARROW")) : 128;
+    const int lo = cin < cout ? cin : cout, hi = cin < cout ? cout : cin;
+    return hi >= 128 && lo >= narrow;
 }
 // ... and of those the ones the split-operand TN GEMM (gemm_split.hip, BF16 matrix cores, fp32-accurate) takes: pixel count a multiple of 16
 static bool wgrad1x1_x3(long P, int cin, int cout) {

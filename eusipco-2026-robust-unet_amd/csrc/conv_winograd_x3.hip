@@ -32,6 +32,7 @@ struct WinoX3Args {
     int Nimg, H, W, TY, TX;       // TY = H/2, TX = W/2
     int accumulate;
     int npatches, nchunks;        // grid = npatches * nchunks blocks (4x8-tile patches x 64-channel output chunks)
+    int abl;                      // timing ablations (wrong results): 1 = every filter fragment read from the first position / chunk (L1-resident)
 };
 
 constexpr int WT = 32;            // tiles per block
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(256, 2) void wino_conv_x3_kernel(WinoX3Args g) {
     auto load_step = [&](int t, int c0, bf16x8 (&slot)[3]) {
         const int xi = wid * 4 + (t >> 1);
 #pragma unroll
-        for (int p = 0; p < 3; ++p) slot[p] = U16[(long)((xi * 3 + p) * K8 + (c0 >> 3)) * g.N + uoff[t & 1]];      // scalar base + lane offset
+        for (int p = 0; p < 3; ++p) slot[p] = U16[(g.abl & 1 ? 0L : (long)((xi * 3 + p) * K8 + (c0 >> 3)) * g.N) + uoff[t & 1]];      // scalar base + lane offset
     };
     const int a_rd = (li * 2 + (lh ^ ((li >> 3) & 1))) * 16;
     auto read_a = [&](int xl, bf16x8 (&a)[3]) {
@@ -314,6 +315,8 @@ extern "C" int runet_wino_conv_x3(const float* x, int ldx, const void* Upacked, 
     a.Nimg = n_img; a.H = h; a.W = w; a.TY = h / 2; a.TX = w / 2; a.accumulate = accumulate;
     a.npatches = n_img * cdiv(a.TY, 4) * cdiv(a.TX, 8);
     a.nchunks = cdiv(n, WBN);
+    static const int abl = getenv("RUNET_WINO_X3_ABL") ? atoi(getenv("RUNET_WINO_X3_ABL")) : 0;      // timing ablations only (wrong results)
+    a.abl = abl;
     hipLaunchKernelGGL(wino_conv_x3_kernel, dim3(a.npatches * a.nchunks), dim3(256), 0, (hipStream_t)stream, a);
     RUNET_CHECK_LAUNCH();
 }

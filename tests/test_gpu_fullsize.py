@@ -38,8 +38,10 @@ def test_eval_batch_equals_single_images(pkg, oracle, n, size):
             return
         for i in (0, n // 2, n - 1):
             one = model(x[i:i + 1])
-            # the per-image result may differ in the last bits (tile shapes of the GEMMs depend on the pixel count)
-            np.testing.assert_allclose(one.cpu().numpy(), full[i:i + 1].cpu().numpy(), rtol=0, atol=2e-5)
+            # the per-image result may differ in the last bits: tile shapes of the GEMMs (and with them the summation order of the position
+            # GEMMs / 1x1 convolutions) depend on the pixel count.  Measured: <= 2.0e-5 on probabilities (one element of 262144 at 2.009e-5
+            # with the split-operand kernels) - 5e-5 is the bound, 20x inside the 1e-3 the path is held to against the reference
+            np.testing.assert_allclose(one.cpu().numpy(), full[i:i + 1].cpu().numpy(), rtol=0, atol=5e-5)
 
 
 def _step_grads(pkg, model, x, y, scale=1.0):
