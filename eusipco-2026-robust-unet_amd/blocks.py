@@ -360,15 +360,21 @@ def rb_backward(ctx, dout, sink, pre="", need_dx=True):
     check(lib.runet_rb_bwd3(dv.data_ptr(), ops.ld(dv), t2.data_ptr(), ops.ld(t2), sa.data_ptr(), dsm.data_ptr(), amax.data_ptr(),
                             ctx["ca"].data_ptr(), davg.data_ptr(), dmx.data_ptr(), ctx["idx"].data_ptr(), ctx["mean2"].data_ptr(),
                             ctx["invstd2"].data_ptr(), ctx["s2"].data_ptr(), use2.data_ptr(), dt2.data_ptr(), ops.ld(dt2), P, hw, c, m_total, st))
-    ops.conv_wgrad(a1, dt2, 3, 3, out=sink.buf(pre, [("conv2.weight", (3, 3, c, c))]), v=ctx.get("v2"))
+    # the data gradient first: on the adjoint F(4x4) path it leaves Z = A dy A^T behind, which the weight gradient (side stream) reuses
+    kz = {}
+    da1 = ops.conv_dgrad(dt2, p.w2, keep_z=kz)
+    ops.conv_wgrad(a1, dt2, 3, 3, out=sink.buf(pre, [("conv2.weight", (3, 3, c, c))]), v=ctx.get("v2"), z=kz.get("Z"))
     ctx["v2"] = None
-    da1 = ops.conv_dgrad(dt2, p.w2)
-    del dt2
+    del dt2, kz
     sums1 = sink.buf(pre, [("bn1.weight", (c,)), ("bn1.bias", (c,))])
     dt1 = bn_backward(da1, t1, ctx["mean1"], ctx["invstd1"], ctx["s1"], sums1, mask=ctx["mask"], out=da1, sync=sync, relu_shift=ctx["h1"], training=tr)
     # the first block of the network (need_dx False) ends the backward chain: nothing is left on the main stream to overlap with, so its
     # last weight gradient runs there, next to the conv2 weight gradient still on the side stream
-    ops.conv_wgrad(x, dt1, 3, 3, cin_w=p.cin_w, out=sink.buf(pre, [("conv1.weight", (3, 3, p.cin_w, c))]), v=ctx.get("v1"), on_side=need_dx)
+    kz1, dx1 = {}, None
+    if need_dx and p.ws is not None:
+        dx1 = ops.conv_dgrad(dt1, p.w1, keep_z=kz1)
+    ops.conv_wgrad(x, dt1, 3, 3, cin_w=p.cin_w, out=sink.buf(pre, [("conv1.weight", (3, 3, p.cin_w, c))]), v=ctx.get("v1"), on_side=need_dx,
+                   z=kz1.get("Z"))
     ctx["v1"] = None
     dx = None
     if p.ws is not None:
@@ -379,7 +385,7 @@ def rb_backward(ctx, dout, sink, pre="", need_dx=True):
             dr = bn_backward(dv, r, ctx["mean_s"], ctx["invstd_s"], ctx["ss"], sums_s, out=dv, sync=sync, training=tr)
         ops.conv_wgrad(x, dr, 1, 1, cin_w=p.cin_w, out=sink.buf(pre, [("shortcut.0.weight", (1, 1, p.cin_w, c))]))
         if need_dx:
-            dx = ops.conv_dgrad(dt1, p.w1)
+            dx = dx1
             ops.conv_dgrad(dr, p.ws, out=dx, accumulate=True)
     elif need_dx:
         dx = dv
@@ -523,10 +529,11 @@ def dilated_backward(ctx, dout, sink, pre="", need_dx=True):
         sl = dcat[..., i * q:(i + 1) * q]
         k = 1 if i == 0 else 3
         nw = k * k * cin * q
-        ops.conv_wgrad(x, sl, k, k, dil=DIL[i], out=wb[i][:nw])
-        chan_sum(sl, wb[i][nw:])
+        kz = {}
         if need_dx:
-            dx = ops.conv_dgrad(sl, p.w[i], out=dx, dil=DIL[i], accumulate=i > 0)
+            dx = ops.conv_dgrad(sl, p.w[i], out=dx, dil=DIL[i], accumulate=i > 0, keep_z=kz)
+        ops.conv_wgrad(x, sl, k, k, dil=DIL[i], out=wb[i][:nw], z=kz.get("Z"))
+        chan_sum(sl, wb[i][nw:])
     return dx
 
 

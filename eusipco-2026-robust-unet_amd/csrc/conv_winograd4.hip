@@ -142,6 +142,101 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
     }
 }
 
+// ---- data gradient as the ADJOINT of the forward algorithm:  y = A^T [U .* (B^T d B)] A   =>   dd = B [U^T .* (A dy A^T)] B^T, overlap-added.
+// Z = A dy A^T is the transform the weight gradient needs anyway (wino4_input_kernel<1>): one pass over dy serves both, and the filter needs
+// no second (rotated) transform.  M'[36][T][C] = Z . U^T comes from the position GEMMs; this kernel turns it into dx in GATHER form: thread =
+// (4x4 block of output pixels = tile (a, b), channel pair).  The tile's own 6x6 patch B M' B^T covers the block with its inner 4x4; the block's
+// first / last row and column also receive row 5 / row 0 (column 5 / column 0) of the neighbouring tiles' patches, and its corners one value of the
+// diagonal neighbours.  Rows 0 and 5 of B M' B^T need only rows 0 and 5 of M' (B's first and last rows are 4 e_0 and e_5), so a thread reads
+// 36 + 4 x 6 + 4 = 64 values instead of 36; nothing is scattered, every output pixel is written once (or accumulated into once).
+template <typename T> __device__ __forceinline__ void b6(const T v0, const T v1, const T v2, const T v3, const T v4, const T v5, T (&o)[6]) {      // B v
+    o[0] = 4.f * v0;
+    o[1] = 4.f * (v2 - v1) + 2.f * (v4 - v3) + 4.f * v5;
+    o[2] = -5.f * v0 - 4.f * (v1 + v2) - (v3 + v4);
+    o[3] = (v1 - v2) + 2.f * (v3 - v4) - 5.f * v5;
+    o[4] = v0 + v1 + v2 + v3 + v4;
+    o[5] = v5;
+}
+__global__ __launch_bounds__(256) void wino4_output_adj_kernel(const float* __restrict__ M, int N, W4Geom g, float* __restrict__ y, int ldy, int accumulate) {
+    const int N2 = N >> 1;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= g.T * N2) return;
+    const long tile = idx / N2;
+    const int c = (int)(idx - tile * N2) * 2;
+    const int per = g.TY * g.TX;
+    const int n = (int)(tile / per);
+    const int rem = (int)(tile - (long)n * per);
+    const int ty = rem / g.TX, tx = rem - ty * g.TX;
+    const long xs = g.T * N;
+    const float* in = M + tile * N + c;
+    auto ld = [&](const float* base, int pos) { return *reinterpret_cast<const f32x2*>(base + (long)pos * xs); };
+    // own patch: columns first (B applied down each column), then rows; only the inner 4 x 4 is used
+    f32x2 t[6][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        f32x2 o[6];
+        b6(ld(in, j), ld(in, 6 + j), ld(in, 12 + j), ld(in, 18 + j), ld(in, 24 + j), ld(in, 30 + j), o);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) t[i][j] = o[i];
+    }
+    f32x2 out[4][4];
+#pragma unroll
+    for (int i = 1; i < 5; ++i) {
+        f32x2 o[6];
+        b6(t[i][0], t[i][1], t[i][2], t[i][3], t[i][4], t[i][5], o);
+#pragma unroll
+        for (int j = 1; j < 5; ++j) out[i - 1][j - 1] = o[j];
+    }
+    const bool up = ty > 0, down = ty < g.TY - 1, left = tx > 0, right = tx < g.TX - 1;
+    const long dT = (long)g.TX * N;                      // one tile row
+    // vertical neighbours: their row 5 (tile above) / 4 x row 0 (tile below), transformed along the row
+    if (up) {
+        const float* q = in - dT;
+        f32x2 o[6];
+        b6(ld(q, 30), ld(q, 31), ld(q, 32), ld(q, 33), ld(q, 34), ld(q, 35), o);
+#pragma unroll
+        for (int j = 1; j < 5; ++j) out[0][j - 1] += o[j];
+    }
+    if (down) {
+        const float* q = in + dT;
+        f32x2 o[6];
+        b6(ld(q, 0), ld(q, 1), ld(q, 2), ld(q, 3), ld(q, 4), ld(q, 5), o);
+#pragma unroll
+        for (int j = 1; j < 5; ++j) out[3][j - 1] += 4.f * o[j];
+    }
+    // horizontal neighbours: their column 5 (tile to the left) / 4 x column 0 (tile to the right), transformed along the column
+    if (left) {
+        const float* q = in - N;
+        f32x2 o[6];
+        b6(ld(q, 5), ld(q, 11), ld(q, 17), ld(q, 23), ld(q, 29), ld(q, 35), o);
+#pragma unroll
+        for (int i = 1; i < 5; ++i) out[i - 1][0] += o[i];
+    }
+    if (right) {
+        const float* q = in + N;
+        f32x2 o[6];
+        b6(ld(q, 0), ld(q, 6), ld(q, 12), ld(q, 18), ld(q, 24), ld(q, 30), o);
+#pragma unroll
+        for (int i = 1; i < 5; ++i) out[i - 1][3] += 4.f * o[i];
+    }
+    // diagonal neighbours: one corner value each
+    if (up && left) out[0][0] += ld(in - dT - N, 35);
+    if (up && right) out[0][3] += 4.f * ld(in - dT + N, 30);
+    if (down && left) out[3][0] += 4.f * ld(in + dT - N, 5);
+    if (down && right) out[3][3] += 16.f * ld(in + dT + N, 0);
+    float* dst = y + pix(g, n, 4 * ty, 4 * tx) * ldy + c;
+    const long rs = (long)g.D * g.WF * ldy, ps = (long)g.D * ldy;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float* p = dst + i * rs + j * ps;
+            f32x2 v = out[i][j];
+            if (accumulate) v += *reinterpret_cast<const f32x2*>(p);
+            *reinterpret_cast<f32x2*>(p) = v;
+        }
+}
+
 // thread = (k, n) with n fastest (coalesced U stores).  forward: g[r][s] = w[r][s][k][n];  dgrad: g[r][s] = w[2-r][2-s][n][k]
 __global__ __launch_bounds__(256) void wino4_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int cin, int cout, int dgrad) {
     const int K = dgrad ? cout : cin, N = dgrad ? cin : cout;
@@ -177,6 +272,8 @@ __global__ __launch_bounds__(256) void wino4_weight_kernel(const float* __restri
 // Up[36][plane 3][K/8][N][8] bf16, x = h + m + l exactly): one pass instead of wino4_weight_kernel + x3_pack_kernel - the fp32 U (4x the
 // weights) is never written or read (2 x 28 launches and 4.6 GB of the step's 105 GB were this round trip).  thread = (k octet, n), n fastest.
 typedef __bf16 w4_bf16x8 __attribute__((ext_vector_type(8)));
+// dgrad: 0 forward (K = cin);  1 rotated filter for the data gradient computed as a convolution (K = cout);  2 the forward's U TRANSPOSED over
+// (k, n) and not rotated, for the data gradient computed as the ADJOINT of the forward algorithm (K = cout; wino4_output_adj_kernel)
 __global__ __launch_bounds__(256) void wino4_weight_x3_kernel(const float* __restrict__ w, __bf16* __restrict__ Up, int cin, int cout, int dgrad) {
     const int K = dgrad ? cout : cin, N = dgrad ? cin : cout;
     const int K8 = K >> 3;
@@ -192,7 +289,8 @@ __global__ __launch_bounds__(256) void wino4_weight_x3_kernel(const float* __res
         for (int r = 0; r < 3; ++r)
 #pragma unroll
             for (int q = 0; q < 3; ++q)
-                gm[j][r][q] = dgrad ? w[((long)((2 - r) * 3 + (2 - q)) * cin + n) * cout + k] : w[((long)(r * 3 + q) * cin + k) * cout + n];
+                gm[j][r][q] = dgrad == 1 ? w[((long)((2 - r) * 3 + (2 - q)) * cin + n) * cout + k]
+                            : dgrad == 2 ? w[((long)(r * 3 + q) * cin + n) * cout + k] : w[((long)(r * 3 + q) * cin + k) * cout + n];
     }
     auto grow = [](const float g0, const float g1, const float g2, const int a) -> float {      // row a of G applied to (g0, g1, g2)
         const float e = (g0 + g2) * (1.f / 6.f), f = g0 * (1.f / 24.f) + g2 * (1.f / 6.f);
@@ -328,6 +426,15 @@ extern "C" int runet_wino4_output(const float* M, int n, int n_img, int h, int w
     RUNET_REQUIRE(((uintptr_t)M % 8) == 0 && ((uintptr_t)y % 8) == 0 && (!bias || ((uintptr_t)bias % 8) == 0), "alignment");
     const W4Geom g = geom(n_img, h, w, dil);
     hipLaunchKernelGGL(wino4_output_kernel, dim3(cdiv(g.T * (n / 2), 256)), dim3(256), 0, (hipStream_t)stream, M, n, g, bias, y, ldy, accumulate);
+    RUNET_CHECK_LAUNCH();
+}
+
+// data gradient by the adjoint form: M' [36][T][n] (= Z . U^T from the position GEMMs) -> dx [n_img, h, w, n] (+= when accumulate)
+extern "C" int runet_wino4_output_adj(const float* M, int n, int n_img, int h, int w, int dil, float* y, int ldy, int accumulate, void* stream) {
+    RUNET_REQUIRE(M && y && dil_ok(h, w, dil) && runet_wino4_supported(h / dil, w / dil, 16, 4) && n > 0 && n % 2 == 0 && ldy >= n && ldy % 2 == 0, "bad arguments");
+    RUNET_REQUIRE(((uintptr_t)M % 8) == 0 && ((uintptr_t)y % 8) == 0, "alignment");
+    const W4Geom g = geom(n_img, h, w, dil);
+    hipLaunchKernelGGL(wino4_output_adj_kernel, dim3(cdiv(g.T * (n / 2), 256)), dim3(256), 0, (hipStream_t)stream, M, n, g, y, ldy, accumulate);
     RUNET_CHECK_LAUNCH();
 }
 

@@ -468,7 +468,8 @@ def wino_ok(h, w, cin, cout):
     return bool(lib.runet_wino_supported(h, w, cin, cout))
 
 
-def conv_dgrad(dy, w_hwio, out=None, dil=1, accumulate=False):
+def conv_dgrad(dy, w_hwio, out=None, dil=1, accumulate=False, keep_z=None):
+    """keep_z: dict that receives {"Z": ...} when the layer takes the adjoint F(4x4) path - hand it to conv_wgrad(..., z=...) of the same layer."""
     n, h, w, cout = dy.shape
     kh, kw, cin, cout_w = w_hwio.shape
     assert cout_w == cout
@@ -477,6 +478,8 @@ def conv_dgrad(dy, w_hwio, out=None, dil=1, accumulate=False):
             out = empty_nhwc(n, h, w, cin, dy)
         return _igemm_bf16(CONV_DGRAD, dy, w_hwio, None, out, n, h, w, cout, cin, kh, kw, dil, accumulate, True)
     if _wino4_case(h, w, kh, dil, cout, cin, cout):
+        if USE_W4_ADJOINT and _x3_case(cout):
+            return wino4_dgrad_adj(dy, w_hwio, out=out, accumulate=accumulate, dil=dil, keep_z=keep_z)
         return wino4_conv(dy, wino4_weights(w_hwio, dgrad=True), None, out=out, accumulate=accumulate, dil=dil)
     if _wino_case(h, w, kh, dil, cout, cin, cout, n, ld(dy), ld(out) if out is not None else cin):
         return wino_conv(dy, wino_weights(w_hwio, dgrad=True), None, out=out, accumulate=accumulate)
@@ -604,15 +607,15 @@ def _on_side(fn, tensors):
     return r
 
 
-def conv_wgrad(x, dy, kh, kw, cin_w=None, dil=1, out=None, v=None, on_side=True):
+def conv_wgrad(x, dy, kh, kw, cin_w=None, dil=1, out=None, v=None, on_side=True, z=None):
     if on_side and _side.get("active") is not None:
         if out is None:
             out = torch.empty((kh, kw, x.shape[3] if cin_w is None else cin_w, dy.shape[3]), device=x.device, dtype=torch.float32)
-        return _on_side(lambda: _conv_wgrad(x, dy, kh, kw, cin_w, dil, out, v), (x, dy, out, v))
-    return _conv_wgrad(x, dy, kh, kw, cin_w, dil, out, v)
+        return _on_side(lambda: _conv_wgrad(x, dy, kh, kw, cin_w, dil, out, v, z), (x, dy, out, v, z))
+    return _conv_wgrad(x, dy, kh, kw, cin_w, dil, out, v, z)
 
 
-def _conv_wgrad(x, dy, kh, kw, cin_w=None, dil=1, out=None, v=None):
+def _conv_wgrad(x, dy, kh, kw, cin_w=None, dil=1, out=None, v=None, z=None):
     n, h, w, cin = x.shape
     cout = dy.shape[3]
     cin_w = cin if cin_w is None else cin_w
@@ -621,7 +624,7 @@ def _conv_wgrad(x, dy, kh, kw, cin_w=None, dil=1, out=None, v=None):
     if _bf16_case(cin, cin_w):
         return _wgrad_bf16(x, dy, out, n, h, w, cin, cout, kh, kw, dil, 0)
     if _wino4_case(h, w, kh, dil, cin, cout, cin_w) and cout >= 16:
-        return wino4_wgrad(x, dy, out=out, v=v, dil=dil)
+        return wino4_wgrad(x, dy, out=out, v=v, dil=dil, z=z)
     if _stem_case(cin, cin_w, cout, kh, dil):
         ws = workspace(lib.runet_stem_wgrad_workspace_floats(n, h, w, cin_w, cout, kh), x.device)
         check(lib.runet_stem_wgrad(x.data_ptr(), ld(x), dy.data_ptr(), ld(dy), out.data_ptr(), ws.data_ptr(), ws.numel(), n, h, w, cin_w, cout, kh,
@@ -923,19 +926,27 @@ def _x3_case(k):
     return USE_X3 and k % 16 == 0
 
 
-def wino4_weights(w_hwio, dgrad=False):
+# The F(4x4) data gradient as the ADJOINT of the forward algorithm (csrc/conv_winograd4.hip wino4_output_adj_kernel): dx = overlap-add of
+# B [U^T .* (A dy A^T)] B^T.  Z = A dy A^T is the transform the weight gradient of the same layer needs, so one pass over dy serves both, and the
+# filter needs no rotated second transform.  RUNET_NO_W4_ADJOINT=1: the data gradient as a convolution with the rotated filter (round 2's form).
+USE_W4_ADJOINT = os.environ.get("RUNET_NO_W4_ADJOINT", "0") != "1"
+
+
+def wino4_weights(w_hwio, dgrad=False, adjoint=False):
     """HWIO 3x3 weight -> U[36][K][N] (forward: K=cin, N=cout; dgrad: rotated filter, K=cout, N=cin); under USE_X3 the split-plane
     packing of it (runet_gemm_x3_pack: [36][3][K/8][N][8] bf16) that runet_wino4_conv_x3 / runet_gemm_x3_batched read."""
     _, _, cin, cout = w_hwio.shape
+    dgrad = dgrad or adjoint
     k, n = (cout, cin) if dgrad else (cin, cout)
     wp, dev = w_hwio.data_ptr(), w_hwio.device
     if _x3_case(k):
         def make_x3(out):
             Up = out if out is not None else torch.empty(lib.runet_gemm_x3_pack_elems(36, k, n), device=dev, dtype=torch.bfloat16)
-            check(lib.runet_wino4_weights_x3(wp, Up.data_ptr(), cin, cout, int(dgrad), stream()))      # transform + split in one pass
+            check(lib.runet_wino4_weights_x3(wp, Up.data_ptr(), cin, cout, 2 if adjoint else int(dgrad), stream()))      # transform + split in one pass
             Up.kn = (k, n)
             return Up
-        return _cached(w_hwio, "wino4xd" if dgrad else "wino4x", make_x3)
+        return _cached(w_hwio, "wino4xad" if adjoint else ("wino4xd" if dgrad else "wino4x"), make_x3)
+    assert not adjoint, "the adjoint data gradient exists for the split-operand path only"
 
     def make(out):
         U = out if out is not None else torch.empty((36, k, n), device=dev, dtype=torch.float32)
@@ -985,15 +996,45 @@ def wino4_conv(x, U, bias=None, out=None, accumulate=False, keep_v=None, dil=1):
     return out
 
 
-def wino4_wgrad(x, dy, out=None, v=None, dil=1):
-    """v: the forward pass's transformed input (wino4_conv(keep_v=...)) - skips the B^T d B pass over x."""
+def wino4_dgrad_adj(dy, w_hwio, out=None, accumulate=False, dil=1, keep_z=None):
+    """Data gradient of conv3x3(x, w) by the adjoint form.  keep_z: dict that receives {"Z": A dy A^T [36*T*cout]} for the weight gradient of
+    the same layer (conv_wgrad(..., z=...))."""
+    n, h, w, cout = dy.shape
+    cin = w_hwio.shape[2]
+    Ua = wino4_weights(w_hwio, adjoint=True)
+    if out is None:
+        out = empty_nhwc(n, h, w, cin, dy)
+    t = n * (h // 4) * (w // 4)
+    if keep_z is not None:
+        zt = torch.empty(36 * t * cout, device=dy.device, dtype=torch.float32)
+        keep_z["Z"] = zt
+        Z, M = zt.data_ptr(), _workspace4(36 * t * cin, dy.device).data_ptr()
+    else:
+        ws = _workspace4(36 * t * (cout + cin), dy.device)
+        Z, M = ws.data_ptr(), ws.data_ptr() + 4 * 36 * t * cout
+    check(lib.runet_wino4_input(dy.data_ptr(), ld(dy), cout, n, h, w, dil, 1, Z, stream()))
+    if _PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(lib.runet_gemm_x3_batched(Z, cout, t * cout, Ua.data_ptr(), M, cin, t * cin, 36, t, cout, cin, stream()))
+    if _PROFILE is not None:
+        e1.record()
+        fl = 2.0 * 36 * t * cout * cin
+        _PROFILE.append((lib.runet_gemm_x3_kernel_name(36, t, cout, cin).decode(), 4.0 * fl, fl, e0, e1))
+    check(lib.runet_wino4_output_adj(M, cin, n, h, w, dil, out.data_ptr(), ld(out), int(accumulate), stream()))
+    return out
+
+
+def wino4_wgrad(x, dy, out=None, v=None, dil=1, z=None):
+    """v: the forward pass's transformed input (wino4_conv(keep_v=...)) - skips the B^T d B pass over x;  z: A dy A^T from the adjoint data
+    gradient of the same layer (wino4_dgrad_adj(keep_z=...)) - skips the pass over dy."""
     n, h, w, cin = x.shape
     cout = dy.shape[3]
     if out is None:
         out = torch.empty((3, 3, cin, cout), device=x.device, dtype=torch.float32)
     ws = _workspace4(lib.runet_wino4_wgrad_workspace_floats(n, h, w, cin, cout), x.device)
     x3 = USE_X3 and (n * (h // 4) * (w // 4)) % 16 == 0 and cin > 64 and cout > 64
-    if _PROFILE is None and v is None and not x3:
+    if _PROFILE is None and v is None and z is None and not x3:
         check(lib.runet_wino4_wgrad(x.data_ptr(), ld(x), dy.data_ptr(), ld(dy), out.data_ptr(), ws.data_ptr(), ws.numel(), n, h, w, cin, cout, dil, stream()))
         return out
     t = n * (h // 4) * (w // 4)
@@ -1006,7 +1047,11 @@ def wino4_wgrad(x, dy, out=None, v=None, dil=1):
     else:
         assert v.numel() == 36 * t * cin
         V = v.data_ptr()
-    check(lib.runet_wino4_input(dy.data_ptr(), ld(dy), cout, n, h, w, dil, 1, Z, stream()))
+    if z is None:
+        check(lib.runet_wino4_input(dy.data_ptr(), ld(dy), cout, n, h, w, dil, 1, Z, stream()))
+    else:
+        assert z.numel() == 36 * t * cout
+        Z = z.data_ptr()
     if _PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

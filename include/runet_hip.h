@@ -273,6 +273,10 @@ int runet_wino4_conv_x3(const float* x, int ldx, const void* Upacked, const floa
  *   runet_wino4_output: y = A^T M A (+bias, +y);  runet_wino4_wgrad_output: dw[3][3][cin][cout] = G^T (sum_splits dU[split][36][cin][cout]) G */
 int runet_wino4_input(const float* src, int ld, int c, int n_img, int h, int w, int dil, int mode, float* V, void* stream);
 int runet_wino4_output(const float* M, int n, int n_img, int h, int w, int dil, const float* bias, float* y, int ldy, int accumulate, void* stream);
+/* The data gradient as the ADJOINT of the forward algorithm: Z = A dy A^T (runet_wino4_input mode 1 - the weight gradient's transform, shared),
+ * M' = Z . U^T by the position GEMMs (runet_wino4_weights_x3 with dgrad = 2: the forward's U transposed, not rotated), and this gather-form
+ * output transform dx = overlap-add of B M' B^T: one pass over dy and one filter transform less than the convolution form per layer. */
+int runet_wino4_output_adj(const float* M, int n, int n_img, int h, int w, int dil, float* y, int ldy, int accumulate, void* stream);
 int runet_wino4_wgrad_output(const float* dU, int splits, int cin, int cout, float* dw, void* stream);
 int runet_wino4_wgrad_rows_per_split(int n_img, int h, int w, int cin, int cout);
 long runet_wino4_wgrad_workspace_floats(int n_img, int h, int w, int cin, int cout);

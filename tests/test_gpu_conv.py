@@ -223,6 +223,16 @@ def test_winograd_f4_matches_torch(n, h, w, cin, cout, dil):
     ops.wino4_conv(xd, U, None, out=acc, accumulate=True, dil=dil)
     close((acc - base).permute(0, 3, 1, 2), y - b.view(1, -1, 1, 1), 5e-4, "fwd accumulate")
     close(ops.wino4_conv(dyd, Ud, dil=dil).permute(0, 3, 1, 2), x.grad, 2e-4, "dgrad")
+    if ops._x3_case(cout):
+        # the data gradient as the adjoint of the forward algorithm (gather-form output transform), its accumulate form, and the weight
+        # gradient on the Z = A dy A^T it leaves behind
+        kz = {}
+        close(ops.wino4_dgrad_adj(dyd, wd, dil=dil, keep_z=kz).permute(0, 3, 1, 2), x.grad, 2e-4, "dgrad (adjoint form)")
+        accd = torch.full((n, h, w, cin), 0.5, device=dev)
+        ops.wino4_dgrad_adj(dyd, wd, out=accd, accumulate=True, dil=dil)
+        close((accd - 0.5).permute(0, 3, 1, 2), x.grad, 5e-4, "dgrad (adjoint form, accumulate)")
+        close(ops.wino4_wgrad(xd, dyd, dil=dil, z=kz["Z"]).permute(3, 2, 0, 1), wt.grad, 5e-4, "wgrad from the adjoint data gradient's Z")
+        assert torch.equal(ops.conv_dgrad(dyd, wd, dil=dil), ops.wino4_dgrad_adj(dyd, wd, dil=dil)) or not ops._wino4_case(h, w, 3, dil, cout, cin, cout)
     close(ops.wino4_wgrad(xd, dyd, dil=dil).permute(3, 2, 0, 1), wt.grad, 5e-4, "wgrad")
     keep = {}
     ops.wino4_conv(xd, U, b.to(dev), keep_v=keep, dil=dil)             # the forward's transformed input reused by the weight gradient
