@@ -110,13 +110,19 @@ class BNState:
 FUSED_BN_STATS = os.environ.get("RUNET_BN_STATS_3", "0") != "1"      # RUNET_BN_STATS_3=1: statistics / combine / finalize as three launches
 
 
-def bn_coeff(x, bn: BNState, training, sm: Small, want_minmax=False, stats_hook=None):
-    """Batch (training) or running (eval) statistics -> (scale, shift, save_mean, save_invstd[, per-(n,c) stats])."""
+def bn_coeff(x, bn: BNState, training, sm: Small, want_minmax=False, stats_hook=None, fused=None):
+    """Batch (training) or running (eval) statistics -> (scale, shift, save_mean, save_invstd[, per-(n,c) stats]).
+    fused: the dict the producing convolution filled (ops.conv_fwd(stats=...)): its epilogue already holds (count, mean, M2) partials of x."""
     n, h, w, c = x.shape
     hw = h * w
     st = ops.stream()
     scale, shift, mean, invstd = sm.f(c), sm.f(c), sm.f(c), sm.f(c)
     nc = None
+    if training and not want_minmax and stats_hook is None and FUSED_BN_STATS and fused and "part" in fused:
+        check(lib.runet_bn_stats_finalize(fused["part"].data_ptr(), fused["nparts"], c, bn.weight.data_ptr(), bn.bias.data_ptr(),
+                                          bn.running_mean.data_ptr(), bn.running_var.data_ptr(), bn.nbt.data_ptr(), BN_MOMENTUM, BN_EPS,
+                                          scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), st))
+        return scale, shift, mean, invstd, None
     if training and not want_minmax and stats_hook is None and FUSED_BN_STATS:
         # no per-image statistics wanted: partials -> batch statistics -> coefficients in two launches
         check(lib.runet_bn_stats(x.data_ptr(), ops.ld(x), n, hw, c, _ws(n, hw, c, x.device).data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(),
@@ -271,16 +277,18 @@ def rb_forward(x, p: RBParams, training, mask=None, save=True, stats_hook=None):
             sm.f(4)                                    # the arena's buffer is allocated on the main stream
             br = ops.side_branch(stats_hook is None)
             with br:
-                r = ops.conv_fwd(x, p.ws)
-                ss, hs, mean_s, invstd_s, _ = bn_coeff(r, p.bns, training, sm)
+                fs = {} if training else None
+                r = ops.conv_fwd(x, p.ws, stats=fs)
+                ss, hs, mean_s, invstd_s, _ = bn_coeff(r, p.bns, training, sm, fused=fs)
     else:
         r, ss, hs, mean_s, invstd_s = x, None, None, None, None
+    f1 = {} if (training and stats_hook is None) else None
     if t1 is None:
-        t1 = ops.conv_fwd(x, p.w1, keep_v=kv1)
+        t1 = ops.conv_fwd(x, p.w1, keep_v=kv1, stats=f1)
     if p.ws is not None and stats_hook is not None:
         (ss, hs, mean_s, invstd_s), (s1, h1, mean1, invstd1) = bn_coeff_pair(r, p.bns, t1, p.bn1, training, sm, stats_hook)
     else:
-        s1, h1, mean1, invstd1, _ = bn_coeff(t1, p.bn1, training, sm, stats_hook=stats_hook)
+        s1, h1, mean1, invstd1, _ = bn_coeff(t1, p.bn1, training, sm, stats_hook=stats_hook, fused=f1)
     use_mask = mask if training else None
     a1 = bn_apply(t1, s1, h1, use_mask, relu=True)
     if not save:
@@ -552,9 +560,10 @@ def gate_x_branch(skip, p: UpGateParams, training, sm, stats_hook=None):
     sm.f(4)
     br = ops.side_branch(stats_hook is None)
     with br:
-        x1 = ops.conv_fwd(skip, p.wx, p.bx)
+        fx = {} if (training and stats_hook is None) else None
+        x1 = ops.conv_fwd(skip, p.wx, p.bx, stats=fx)
         # SyncBN: the statistics wait for gate_forward, where they share W_g's message
-        cx = bn_coeff(x1, p.bnx, training, sm)[:4] if stats_hook is None else None
+        cx = bn_coeff(x1, p.bnx, training, sm, fused=fx)[:4] if stats_hook is None else None
     return br, x1, cx
 
 
@@ -566,13 +575,14 @@ def gate_forward(up, skip, p: UpGateParams, training, att_out, sm, stats_hook=No
     st = ops.stream()
     if xb is None:
         xb = gate_x_branch(skip, p, training, sm, stats_hook)
-    g1 = ops.conv_fwd(up, p.wg, p.bg)
+    fg = {} if (training and stats_hook is None) else None
+    g1 = ops.conv_fwd(up, p.wg, p.bg, stats=fg)
     br, x1, cx = xb
     if cx is None:
         br.join(x1)
         (sg, hg, mean_g, invstd_g), cx = bn_coeff_pair(g1, p.bng, x1, p.bnx, training, sm, stats_hook)
     else:
-        sg, hg, mean_g, invstd_g, _ = bn_coeff(g1, p.bng, training, sm)
+        sg, hg, mean_g, invstd_g, _ = bn_coeff(g1, p.bng, training, sm, fused=fg)
         br.join(x1)
     sx, hx, mean_x, invstd_x = cx
     s = torch.empty((n, h, w, 1), device=skip.device, dtype=torch.float32)

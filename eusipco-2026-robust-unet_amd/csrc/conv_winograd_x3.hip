@@ -32,6 +32,7 @@ struct WinoX3Args {
     int Nimg, H, W, TY, TX;       // TY = H/2, TX = W/2
     int accumulate;
     int npatches, nchunks;        // grid = npatches * nchunks blocks (4x8-tile patches x 64-channel output chunks)
+    float* stats;                 // nullptr, or [npatches][N][3]: (count, mean, M2) per output channel over the block's pixels (BatchNorm statistics)
     int abl;                      // timing ablations (wrong results): 1 = every filter fragment read from the first position / chunk (L1-resident)
 };
 
@@ -44,6 +45,7 @@ constexpr int VPLANE = 16 * WT * 32;      // bytes of one bf16 plane of V: 16 po
 __global__ __launch_bounds__(256, 2) void wino_conv_x3_kernel(WinoX3Args g) {
     __shared__ __attribute__((aligned(16))) unsigned char Vp[3 * VPLANE];   // 48 KB; reused as M[16][32][16] fp32 in the epilogue
     __shared__ __attribute__((aligned(16))) float R[RH * RW * RPS];         // 17 KB raw input halo of the current 16-channel chunk
+    __shared__ float sred[4 * 4 * 8 * 2 * 3];                               // statistics: [pass][wave][channel pair][2][count, mean, M2]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
@@ -204,6 +206,10 @@ __global__ __launch_bounds__(256, 2) void wino_conv_x3_kernel(WinoX3Args g) {
                 }
         }
         __syncthreads();
+        float2 px[4];
+        float npx = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) px[q] = make_float2(0.f, 0.f);
         if (e_ok) {
             float2 m[16];
 #pragma unroll
@@ -230,8 +236,55 @@ __global__ __launch_bounds__(256, 2) void wino_conv_x3_kernel(WinoX3Args g) {
                     }
                     *reinterpret_cast<float2*>(d0) = o0;
                     *reinterpret_cast<float2*>(d1) = o1;
+                    px[2 * i] = o0; px[2 * i + 1] = o1;
                 }
+                npx = 4.f;
             }
+        }
+        if (g.stats) {
+            // BatchNorm statistics of the four pixels x two channels this thread just stored: (count, mean, M2) in registers, Chan-combined
+            // over the eight tiles of the wave that share the channel pair (lanes 8, 16, 32 apart), one row per wave into LDS
+            float cnt = npx;
+            float2 mean = make_float2(0.f, 0.f), m2 = make_float2(0.f, 0.f);
+            if (npx > 0.f) {
+                mean = make_float2(0.25f * (px[0].x + px[1].x + px[2].x + px[3].x), 0.25f * (px[0].y + px[1].y + px[2].y + px[3].y));
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const float dx_ = px[q].x - mean.x, dy_ = px[q].y - mean.y; m2.x += dx_ * dx_; m2.y += dy_ * dy_; }
+            }
+#pragma unroll
+            for (int o = 8; o < 64; o <<= 1) {
+                const float c2 = __shfl_xor(cnt, o, 64);
+                const float2 mo = make_float2(__shfl_xor(mean.x, o, 64), __shfl_xor(mean.y, o, 64));
+                const float2 qo = make_float2(__shfl_xor(m2.x, o, 64), __shfl_xor(m2.y, o, 64));
+                const float nt = cnt + c2;
+                if (nt > 0.f) {
+                    const float f1 = c2 / nt, f2 = cnt * c2 / nt;
+                    const float ddx = mo.x - mean.x, ddy = mo.y - mean.y;
+                    m2 = make_float2(m2.x + qo.x + ddx * ddx * f2, m2.y + qo.y + ddy * ddy * f2);
+                    mean = make_float2(mean.x + ddx * f1, mean.y + ddy * f1);
+                }
+                cnt = nt;
+            }
+            if (lane < 8) {
+                float* o = &sred[((pass * 4 + wid) * 8 + lane) * 6];
+                o[0] = cnt; o[1] = mean.x; o[2] = m2.x; o[3] = cnt; o[4] = mean.y; o[5] = m2.y;
+            }
+        }
+    }
+    if (g.stats) {
+        __syncthreads();
+        if (tid < 64 && n0 + tid < g.N) {           // channel n0 + tid = pass * 16 + pair * 2 + ch: the four waves' rows in wave order
+            const int pass = tid >> 4, pair = (tid & 15) >> 1, chn = tid & 1;
+            float cnt = 0.f, mean = 0.f, m2 = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < 4; ++wv) {
+                const float* a = &sred[(((pass * 4 + wv) * 8 + pair) * 2 + chn) * 3];
+                const float nt = cnt + a[0], dlt = a[1] - mean;
+                if (nt > 0.f) { m2 = m2 + a[2] + dlt * dlt * (cnt * a[0] / nt); mean = mean + dlt * (a[0] / nt); }
+                cnt = nt;
+            }
+            float* o = g.stats + ((long)bpatch * g.N + n0 + tid) * 3;
+            o[0] = cnt; o[1] = mean; o[2] = m2;
         }
     }
 }
@@ -303,8 +356,25 @@ extern "C" int runet_wino_weights_x3(const float* w_hwio, void* Upacked, int cin
     RUNET_CHECK_LAUNCH();
 }
 
+extern "C" int runet_wino_conv_x3_stats_parts(int n_img, int h, int w) { return n_img * cdiv(h / 2, 4) * cdiv(w / 2, 8); }
+
+static int wino_conv_x3_launch(const float* x, int ldx, const void* Upacked, const float* bias, float* y, int ldy, int n_img, int h, int w, int k,
+                               int n, int accumulate, float* stats, void* stream);
+
 extern "C" int runet_wino_conv_x3(const float* x, int ldx, const void* Upacked, const float* bias, float* y, int ldy, int n_img, int h, int w, int k,
                                   int n, int accumulate, void* stream) {
+    return wino_conv_x3_launch(x, ldx, Upacked, bias, y, ldy, n_img, h, w, k, n, accumulate, nullptr, stream);
+}
+
+// runet_wino_conv_x3 that also leaves the BatchNorm statistics partials of its output behind: stats [runet_wino_conv_x3_stats_parts][n][3]
+extern "C" int runet_wino_conv_x3_stats(const float* x, int ldx, const void* Upacked, const float* bias, float* y, int ldy, int n_img, int h, int w,
+                                        int k, int n, int accumulate, float* stats, void* stream) {
+    RUNET_REQUIRE(stats, "stats must not be NULL");
+    return wino_conv_x3_launch(x, ldx, Upacked, bias, y, ldy, n_img, h, w, k, n, accumulate, stats, stream);
+}
+
+static int wino_conv_x3_launch(const float* x, int ldx, const void* Upacked, const float* bias, float* y, int ldy, int n_img, int h, int w, int k,
+                               int n, int accumulate, float* stats, void* stream) {
     RUNET_REQUIRE(x && Upacked && y, "null pointer");
     RUNET_REQUIRE(runet_wino_supported(h, w, k, n), "shape not supported by the Winograd kernel (H, W even; K multiple of 16; N even)");
     RUNET_REQUIRE(ldx >= k && ldx % 4 == 0 && ldy >= n && ldy % 2 == 0, "pixel strides must cover the channels (ldx: multiple of 4, ldy: even)");
@@ -317,6 +387,7 @@ extern "C" int runet_wino_conv_x3(const float* x, int ldx, const void* Upacked, 
     a.nchunks = cdiv(n, WBN);
     static const int abl = getenv("RUNET_WINO_X3_ABL") ? atoi(getenv("RUNET_WINO_X3_ABL")) : 0;      // timing ablations only (wrong results)
     a.abl = abl;
+    a.stats = stats;
     hipLaunchKernelGGL(wino_conv_x3_kernel, dim3(a.npatches * a.nchunks), dim3(256), 0, (hipStream_t)stream, a);
     RUNET_CHECK_LAUNCH();
 }

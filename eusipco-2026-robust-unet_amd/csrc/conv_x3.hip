@@ -32,6 +32,7 @@ struct X3ConvArgs {
     int a_scale, c_scale;                // 1 or 2: source / destination pixel of row (img, h, w) = (img, h * s [+ zh], w * s [+ zw]) in an (H s) x (W s) image
     int ntaps;                           // taps in the k-loop (1, or 4 = the transposed data gradient: source offset (a * W a_scale + b) pixels)
     int accumulate;
+    float* stats;                        // nullptr, or [gm][n][3]: (count, mean, M2) of every output channel over the block's rows (BatchNorm statistics)
     int gm, gn, gz;                      // row tiles, column tiles, z (4 = transposed forward: z is the tap AND the destination offset)
 };
 
@@ -216,15 +217,73 @@ __global__ __launch_bounds__(256, 2) void conv_nn_x3_kernel(X3ConvArgs g) {
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] += bv[b];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int rl = wm0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             if (m0 + rl < g.rows) {
                 float* crow = g.c + dst_tab[rl];
 #pragma unroll
                 for (int b = 0; b < TN; ++b)
-                    if (colv[b] < g.n) crow[colv[b]] = acc[a][b][r] + bv[b];
+                    if (colv[b] < g.n) crow[colv[b]] = acc[a][b][r];
             }
         }
+    if (g.stats) {
+        // BatchNorm statistics of what was just stored, per output channel over this block's 128 rows (the pass over the tensor that
+        // chan_stats_partial would make): a lane holds 32 rows of its column(s) -> two-pass (mean, M2) in registers, Chan-combined with the
+        // other lane half (xor 32) and, through LDS, with the wave that holds the other 64 rows.  Fixed order: bitwise reproducible.
+        float* xch = reinterpret_cast<float*>(smem);                       // [2 row halves][BN columns][3]: the stages are dead by now
+        lds_barrier();
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            float cnt = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const bool ok = m0 + wm0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh < g.rows;
+                    cnt += ok ? 1.f : 0.f;
+                    s1 += ok ? acc[a][b][r] : 0.f;
+                }
+            float mean = cnt > 0.f ? s1 / cnt : 0.f, m2 = 0.f;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const bool ok = m0 + wm0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh < g.rows;
+                    const float d = acc[a][b][r] - mean;
+                    m2 += ok ? d * d : 0.f;
+                }
+            // the other lane half (rows + 4)
+            const float cnt_o = __shfl_xor(cnt, 32, 64), mean_o = __shfl_xor(mean, 32, 64), m2_o = __shfl_xor(m2, 32, 64);
+            {
+                const float nt = cnt + cnt_o, dlt = mean_o - mean;
+                if (nt > 0.f) { m2 = m2 + m2_o + dlt * dlt * (cnt * cnt_o / nt); mean = mean + dlt * (cnt_o / nt); }
+                cnt = nt;
+            }
+            if (lh == 0) {
+                float* o = xch + (((wid >> 1) * BN) + wn0 + b * 32 + li) * 3;
+                o[0] = cnt; o[1] = mean; o[2] = m2;
+            }
+        }
+        lds_barrier();
+        for (int cl = tid; cl < BN; cl += 256) {
+            const int col = n0 + cl;
+            if (col < g.n) {
+                const float* a0 = xch + cl * 3;
+                const float* a1 = xch + (BN + cl) * 3;
+                float cnt = a0[0], mean = a0[1], m2 = a0[2];
+                const float nt = cnt + a1[0], dlt = a1[1] - mean;
+                if (nt > 0.f) { m2 = m2 + a1[2] + dlt * dlt * (cnt * a1[0] / nt); mean = mean + dlt * (a1[0] / nt); }
+                float* o = g.stats + ((long)mt * g.n + col) * 3;
+                o[0] = nt; o[1] = mean; o[2] = m2;
+            }
+        }
+    }
 }
 
 // w (fp32) -> split planes dst[z][plane 3][k/8][n][8] bf16 with B_z[kk][col] = w[z * stride_z + kk * sk + col * sn]; thread = (z, octet, column)
@@ -296,8 +355,25 @@ extern "C" const char* runet_conv_x3_kernel_name(int n_img, int h, int w_, int c
 
 // h, w_: the iteration space - the image the 1x1 convolution runs over; for both transposed modes the LOW-resolution image (the
 // forward's input / the data gradient's output), the other side being 2h x 2w_.
+extern "C" int runet_conv_x3_stats_parts(int n_img, int h, int w_) { return cdiv((long)n_img * h * w_, 128); }
+
+static int conv_x3_launch(const float* x, int ldx, const void* wpacked, const float* bias, float* y, int ldy, int n_img, int h, int w_, int cin,
+                          int cout, int mode, int accumulate, float* stats, void* stream);
+
 extern "C" int runet_conv_x3(const float* x, int ldx, const void* wpacked, const float* bias, float* y, int ldy, int n_img, int h, int w_, int cin,
                              int cout, int mode, int accumulate, void* stream) {
+    return conv_x3_launch(x, ldx, wpacked, bias, y, ldy, n_img, h, w_, cin, cout, mode, accumulate, nullptr, stream);
+}
+
+// runet_conv_x3 (1x1 modes only) that also leaves the BatchNorm statistics partials of its output behind: stats [runet_conv_x3_stats_parts][cout][3]
+extern "C" int runet_conv_x3_stats(const float* x, int ldx, const void* wpacked, const float* bias, float* y, int ldy, int n_img, int h, int w_, int cin,
+                                   int cout, int mode, int accumulate, float* stats, void* stream) {
+    RUNET_REQUIRE(stats && (mode == RUNET_CONV_FWD || mode == RUNET_CONV_DGRAD), "statistics: 1x1 modes only, stats must not be NULL");
+    return conv_x3_launch(x, ldx, wpacked, bias, y, ldy, n_img, h, w_, cin, cout, mode, accumulate, stats, stream);
+}
+
+static int conv_x3_launch(const float* x, int ldx, const void* wpacked, const float* bias, float* y, int ldy, int n_img, int h, int w_, int cin,
+                          int cout, int mode, int accumulate, float* stats, void* stream) {
     RUNET_REQUIRE(x && wpacked && y, "null pointer");
     RUNET_REQUIRE(runet_conv_x3_supported(cin, cout, mode), "shape / mode not supported (cin: multiple of 16, cout: multiple of 4)");
     RUNET_REQUIRE(n_img > 0 && h > 0 && w_ > 0 && (long)n_img * h * w_ * 4 < (1L << 31), "iteration space empty or too large");
@@ -306,6 +382,7 @@ extern "C" int runet_conv_x3(const float* x, int ldx, const void* wpacked, const
     X3ConvArgs g{};
     g.a = x; g.lda = ldx; g.b = (const __bf16*)wpacked; g.sb = 3L * cin * cout; g.bias = bias; g.c = y; g.ldc = ldy;
     g.rows = n_img * h * w_; g.k = cin; g.n = cout; g.H = h; g.W = w_; g.a_scale = 1; g.c_scale = 1; g.ntaps = 1; g.accumulate = accumulate; g.gz = 1;
+    g.stats = stats;
     if (mode == RUNET_CONVT_FWD) { g.c_scale = 2; g.gz = 4; }
     if (mode == RUNET_CONVT_DGRAD) { g.a_scale = 2; g.ntaps = 4; }
     g.gm = cdiv(g.rows, 128);

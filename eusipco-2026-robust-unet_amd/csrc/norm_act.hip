@@ -623,6 +623,17 @@ extern "C" int runet_bn_stats(const float* x, int ld, int n_img, int hw, int c, 
     RUNET_CHECK_LAUNCH();
 }
 
+// Second half of runet_bn_stats on partials a PRODUCING kernel wrote in its epilogue (runet_conv_x3 / runet_wino_conv_x3 with a `stats`
+// pointer): part[nparts][c][3] = (count, mean, M2) of disjoint pixel sets that together cover the tensor.
+extern "C" int runet_bn_stats_finalize(const float* part, int nparts, int c, const float* gamma, const float* beta, float* run_mean, float* run_var,
+                                       long long* num_batches_tracked, float momentum, float eps, float* scale, float* shift, float* save_mean,
+                                       float* save_invstd, void* stream) {
+    RUNET_REQUIRE(part && scale && shift && nparts > 0 && c > 0, "bad arguments");
+    hipLaunchKernelGGL(chan_stats_finalize_kernel, dim3(c), dim3(TPB), 0, (hipStream_t)stream, part, c, nparts, gamma, beta, run_mean, run_var,
+                       num_batches_tracked, momentum, eps, scale, shift, save_mean, save_invstd);
+    RUNET_CHECK_LAUNCH();
+}
+
 extern "C" int runet_bn_finalize(const float* mean_nc, const float* m2_nc, int n_img, int c, long hw, const float* gamma,
                                  const float* beta, float* run_mean, float* run_var, long long* num_batches_tracked,
                                  float momentum, float eps, int training, float* scale, float* shift, float* save_mean,

@@ -383,15 +383,32 @@ def conv_x3_weights(w_hwio, mode):
     return _cached(w_hwio, _X3_KIND[mode], make)
 
 
-def _conv_x3(mode, x, w_hwio, bias, out, n, h, w, cin, cout, accumulate):
+# BatchNorm statistics taken in the producing convolution's epilogue (runet_conv_x3_stats / runet_wino_conv_x3_stats) instead of by a pass of
+# runet_bn_stats over the tensor; RUNET_NO_EPILOGUE_STATS=1: the separate pass everywhere.
+EPILOGUE_STATS = os.environ.get("RUNET_NO_EPILOGUE_STATS", "0") != "1"
+
+
+def _stats_buf(stats, nparts, c, dev):
+    """stats: the caller's dict - receives the partials buffer [nparts][c][3] and its row count (blocks.bn_coeff(fused=...) consumes them)."""
+    part = torch.empty(nparts * c * 3, device=dev, dtype=torch.float32)
+    stats["part"], stats["nparts"] = part, nparts
+    return part.data_ptr()
+
+
+def _conv_x3(mode, x, w_hwio, bias, out, n, h, w, cin, cout, accumulate, stats=None):
     """h, w: the image the 1x1 convolution runs over; the low-resolution side for the transposed modes."""
     wp = conv_x3_weights(w_hwio, mode)
     prof = _PROFILE is not None
     if prof:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(lib.runet_conv_x3(x.data_ptr(), ld(x), wp.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(), ld(out), n, h, w,
-                            cin, cout, mode, int(accumulate), stream()))
+    if stats is not None and EPILOGUE_STATS and mode == CONV_FWD:
+        sp = _stats_buf(stats, lib.runet_conv_x3_stats_parts(n, h, w), cout, x.device)
+        check(lib.runet_conv_x3_stats(x.data_ptr(), ld(x), wp.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(), ld(out), n, h, w,
+                                      cin, cout, mode, int(accumulate), sp, stream()))
+    else:
+        check(lib.runet_conv_x3(x.data_ptr(), ld(x), wp.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(), ld(out), n, h, w,
+                                cin, cout, mode, int(accumulate), stream()))
     if prof:
         e1.record()
         fl = 2.0 * n * h * w * (4 if mode in (CONVT_FWD, CONVT_DGRAD) else 1) * cin * cout
@@ -399,7 +416,9 @@ def _conv_x3(mode, x, w_hwio, bias, out, n, h, w, cin, cout, accumulate):
     return out
 
 
-def conv_fwd(x, w_hwio, bias=None, out=None, dil=1, accumulate=False, keep_v=None):
+def conv_fwd(x, w_hwio, bias=None, out=None, dil=1, accumulate=False, keep_v=None, stats=None):
+    """stats: dict; when the kernel that serves this convolution can take the BatchNorm statistics of its output in its epilogue it fills
+    stats["part"] / stats["nparts"] (blocks.bn_coeff(fused=stats) then skips its pass over the tensor), otherwise leaves it empty."""
     n, h, w, cin = x.shape
     kh, kw, cin_w, cout = w_hwio.shape
     if _bf16_case(cin, cin_w):
@@ -409,11 +428,11 @@ def conv_fwd(x, w_hwio, bias=None, out=None, dil=1, accumulate=False, keep_v=Non
     if _wino4_case(h, w, kh, dil, cin, cout, cin_w):
         return wino4_conv(x, wino4_weights(w_hwio), bias, out=out, accumulate=accumulate, keep_v=keep_v, dil=dil)
     if _wino_case(h, w, kh, dil, cin, cout, cin_w, n, ld(x), ld(out) if out is not None else cout):
-        return wino_conv(x, wino_weights(w_hwio), bias, out=out, accumulate=accumulate)
+        return wino_conv(x, wino_weights(w_hwio), bias, out=out, accumulate=accumulate, stats=stats)
     if out is None:
         out = empty_nhwc(n, h, w, cout, x)
     if kh == 1 and _conv_x3_case(x, cin, cin_w, cout):
-        return _conv_x3(CONV_FWD, x, w_hwio, bias, out, n, h, w, cin, cout, accumulate)
+        return _conv_x3(CONV_FWD, x, w_hwio, bias, out, n, h, w, cin, cout, accumulate, stats=stats)
     _igemm(CONV_FWD, x.data_ptr(), ld(x), w_hwio.data_ptr(), bias.data_ptr() if bias is not None else None,
            out.data_ptr(), ld(out), n, h, w, cin, cin_w, cout, kh, kw, dil, int(accumulate))
     return out
@@ -444,7 +463,7 @@ def wino_weights(w_hwio, dgrad=False):
     return _cached(w_hwio, "wino2d" if dgrad else "wino2", make)
 
 
-def wino_conv(x, U, bias=None, out=None, accumulate=False):
+def wino_conv(x, U, bias=None, out=None, accumulate=False, stats=None):
     """3x3 'same' convolution (or its data gradient, with dgrad weights) through the fused Winograd kernel."""
     n, h, w, k = x.shape
     x3 = U.dtype == torch.bfloat16                      # split-plane filter (wino_weights under USE_X3)
@@ -454,9 +473,14 @@ def wino_conv(x, U, bias=None, out=None, accumulate=False):
     if _PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    fn = lib.runet_wino_conv_x3 if x3 else lib.runet_wino_conv
-    check(fn(x.data_ptr(), ld(x), U.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(), ld(out),
-             n, h, w, k, nn_, int(accumulate), stream()))
+    if x3 and stats is not None and EPILOGUE_STATS:
+        sp = _stats_buf(stats, lib.runet_wino_conv_x3_stats_parts(n, h, w), nn_, x.device)
+        check(lib.runet_wino_conv_x3_stats(x.data_ptr(), ld(x), U.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(), ld(out),
+                                           n, h, w, k, nn_, int(accumulate), sp, stream()))
+    else:
+        fn = lib.runet_wino_conv_x3 if x3 else lib.runet_wino_conv
+        check(fn(x.data_ptr(), ld(x), U.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(), ld(out),
+                 n, h, w, k, nn_, int(accumulate), stream()))
     if _PROFILE is not None:
         e1.record()
         fl = 2.0 * n * h * w * 9 * k * nn_

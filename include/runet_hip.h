@@ -84,6 +84,12 @@ long runet_wino_x3_pack_elems(int k, int n);
 int runet_wino_weights_x3(const float* w_hwio, void* Upacked, int cin, int cout, int dgrad, void* stream);
 int runet_wino_conv_x3(const float* x, int ldx, const void* Upacked, const float* bias, float* y, int ldy, int n_img, int h, int w, int k, int n,
                        int accumulate, void* stream);
+/* ... and with the BatchNorm statistics of its output (Main_Final.py:158,160: the BatchNorm2d behind each convolution) taken in the epilogue
+ * instead of by a pass of runet_bn_stats over the tensor: stats [runet_wino_conv_x3_stats_parts(n_img, h, w)][n][3] = (count, mean, M2) per
+ * block of pixels; runet_bn_stats_finalize turns them into the coefficients (the second kernel of runet_bn_stats). */
+int runet_wino_conv_x3_stats_parts(int n_img, int h, int w);
+int runet_wino_conv_x3_stats(const float* x, int ldx, const void* Upacked, const float* bias, float* y, int ldy, int n_img, int h, int w, int k,
+                             int n, int accumulate, float* stats, void* stream);
 
 /* Winograd-domain weight gradient of the same convolutions: dw[3][3][cin][cout] = G^T [sum_tiles (B^T x B).*(A dy A^T)] G.
  * workspace: >= runet_wino_wgrad_workspace_floats floats (partial slabs, summed in a fixed order).  H, W even. */
@@ -103,6 +109,11 @@ int runet_chan_stats(const float* x, int ld, int n_img, int hw, int c, float* wo
 /* training != 0: batch statistics over n_img*hw values from (mean_nc, m2_nc); updates run_mean/run_var (momentum,
  * unbiased variance) and *num_batches_tracked += 1 when those pointers are non-NULL; writes save_mean/save_invstd.
  * training == 0: statistics = run_mean/run_var.  Outputs scale = gamma*invstd, shift = beta - mean*scale. */
+/* coefficients from statistics partials part[nparts][c][3] = (count, mean, M2) of disjoint pixel sets (written by runet_conv_x3_stats /
+ * runet_wino_conv_x3_stats): the second kernel of runet_bn_stats on its own */
+int runet_bn_stats_finalize(const float* part, int nparts, int c, const float* gamma, const float* beta, float* run_mean, float* run_var,
+                            long long* num_batches_tracked, float momentum, float eps, float* scale, float* shift, float* save_mean,
+                            float* save_invstd, void* stream);
 int runet_bn_finalize(const float* mean_nc, const float* m2_nc, int n_img, int c, long hw, const float* gamma, const float* beta,
                       float* run_mean, float* run_var, long long* num_batches_tracked, float momentum, float eps, int training,
                       float* scale, float* shift, float* save_mean, float* save_invstd, void* stream);
@@ -250,6 +261,10 @@ int runet_conv_x3_pack(const float* w, void* packed, int cin, int cout, int mode
 int runet_conv_x3(const float* x, int ldx, const void* wpacked, const float* bias, float* y, int ldy, int n_img, int h, int w, int cin, int cout,
                   int mode, int accumulate, void* stream);
 const char* runet_conv_x3_kernel_name(int n_img, int h, int w, int cout, int mode);
+/* the 1x1 modes with the BatchNorm statistics of the output taken in the epilogue: stats [runet_conv_x3_stats_parts(n_img, h, w)][cout][3] */
+int runet_conv_x3_stats_parts(int n_img, int h, int w);
+int runet_conv_x3_stats(const float* x, int ldx, const void* wpacked, const float* bias, float* y, int ldy, int n_img, int h, int w, int cin, int cout,
+                        int mode, int accumulate, float* stats, void* stream);
 
 /* ---- Winograd F(4x4,3x3), unfused, for the deep 3x3 convolutions (Main_Final.py:157,159 at >= 256 channels) and their autograd ----
  * U [36][K][N] from runet_wino4_weights (dgrad != 0: rotated filter, K = cout, N = cin).  conv: x [n,h,w,K] -> y [n,h,w,N] ('same'), H, W % 4 == 0.

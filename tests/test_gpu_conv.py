@@ -344,7 +344,7 @@ def test_conv_x3_matches_torch(n, h, w, ci, co, monkeypatch):
     xd, w1d, wtd, bd = nhwc(x), w1.detach().float().permute(2, 3, 1, 0).contiguous().to(dev), wt.detach().float().permute(2, 3, 0, 1).contiguous().to(dev), b.float().to(dev)
     seen = []
     real = ops._conv_x3
-    monkeypatch.setattr(ops, "_conv_x3", lambda mode, *a: (seen.append(mode), real(mode, *a))[1])
+    monkeypatch.setattr(ops, "_conv_x3", lambda mode, *a, **kw: (seen.append(mode), real(mode, *a, **kw))[1])
     close(ops.conv_fwd(xd, w1d, bd), y1, "1x1 forward")
     # channel-slice source and destination (concat buffers), accumulate
     big = torch.zeros(n, h, w, ci + 32, device=dev)
@@ -368,3 +368,39 @@ def test_conv_x3_matches_torch(n, h, w, ci, co, monkeypatch):
     # every call whose contraction is a multiple of 16 channels took the split-operand kernel (data gradients contract over `co`)
     want = [ops.CONV_FWD, ops.CONVT_FWD] + ([ops.CONV_DGRAD, ops.CONVT_DGRAD] if co % 16 == 0 else [])
     assert sorted(set(seen)) == sorted(want), seen
+
+
+@pytest.mark.parametrize("n,h,w,ci,co,k", [(2, 16, 16, 128, 128, 1), (3, 10, 12, 256, 64, 1), (1, 6, 10, 128, 384, 1), (2, 32, 32, 64, 64, 3),
+                                           (2, 20, 28, 32, 96, 3), (1, 8, 16, 16, 64, 3), (16, 64, 64, 128, 64, 3)])
+def test_epilogue_statistics_equal_the_separate_pass(n, h, w, ci, co, k, monkeypatch):
+    """BatchNorm statistics taken in the producing convolution's epilogue (runet_conv_x3_stats, runet_wino_conv_x3_stats +
+    runet_bn_stats_finalize) against the separate pass over the stored tensor (runet_bn_stats): scale / shift / saved mean / inverse
+    standard deviation and the running statistics agree to 2e-6 relative (both are Chan combinations of exact per-block moments; the
+    partition of the pixels differs), also with ragged row / tile counts and a bias."""
+    ops = _ops()
+    blocks = importlib.import_module("eusipco-2026-robust-unet_amd.blocks")
+    monkeypatch.setattr(ops, "CONV_X3_MIN_K", 16)
+    monkeypatch.setattr(ops, "CONV_X3_WIDE_N", 4)
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(n + h + ci + co)
+    x = (torch.randn(n, h, w, ci, generator=g) + 0.3).to(dev)
+    wt = (torch.randn(k, k, ci, co, generator=g) / (k * k * ci) ** 0.5).to(dev)
+    b = torch.randn(co, generator=g).to(dev)
+
+    def bn_state():
+        return blocks.BNState(torch.full((co,), 1.5, device=dev), torch.full((co,), -0.25, device=dev), torch.zeros(co, device=dev),
+                              torch.ones(co, device=dev), torch.zeros((), device=dev, dtype=torch.int64))
+    st = {}
+    y = ops.conv_fwd(x, wt, b, stats=st)
+    assert "part" in st, "this shape should have taken a kernel with epilogue statistics"
+    bn_a, bn_b = bn_state(), bn_state()
+    got = blocks.bn_coeff(y, bn_a, True, blocks.Small(dev), fused=st)[:4]
+    ref = blocks.bn_coeff(y, bn_b, True, blocks.Small(dev))[:4]
+    for a, r, name in zip(got, ref, ("scale", "shift", "mean", "invstd")):
+        err = float((a - r).abs().max() / r.abs().max())
+        assert err <= 2e-6, (name, err)
+    assert float((bn_a.running_mean - bn_b.running_mean).abs().max()) <= 2e-6 * float(bn_b.running_mean.abs().max() + 1e-3)
+    assert float((bn_a.running_var - bn_b.running_var).abs().max() / bn_b.running_var.abs().max()) <= 2e-6
+    assert int(bn_a.nbt) == 1 and int(bn_b.nbt) == 1
+    # the convolution's own result is unchanged by asking for statistics
+    assert torch.equal(y, ops.conv_fwd(x, wt, b))
