@@ -984,6 +984,14 @@ static bool wgrad1x1_x3(long P, int cin, int cout) {
     return !off && P % 16 == 0;
 }
 
+// the transposed convolution's weight gradient on the split-operand TN GEMM: image width a multiple of 16 (a k-step's rows share an image row),
+// both channel counts >= RUNET_CONVT_WGRAD_X3_MIN [64]
+static bool convt_wgrad_x3(long P, int w_, int cin, int cout) {
+    static const bool off = (getenv("RUNET_NO_X3") && atoi(getenv("RUNET_NO_X3")) != 0) || (getenv("RUNET_NO_CONVT_WGRAD_X3") && atoi(getenv("RUNET_NO_CONVT_WGRAD_X3")) != 0);
+    static const int lo = getenv("RUNET_CONVT_WGRAD_X3_MIN") ? atoi(getenv("RUNET_CONVT_WGRAD_X3_MIN")) : 64;
+    return !off && w_ % 16 == 0 && P % 16 == 0 && P < (1L << 31) && cin >= lo && cout >= lo;
+}
+
 extern "C" long runet_conv_wgrad_workspace_floats(int n_img, int h, int w_, int cin_w, int cout, int kh, int kw) {
     if (kh == 1 && kw == 1) {
         const long P = (long)n_img * h * w_;
@@ -993,6 +1001,22 @@ extern "C" long runet_conv_wgrad_workspace_floats(int n_img, int h, int w_, int 
         return direct > tile ? direct : tile;
     }
     if (kh == 3 && kw == 3 && cin_w <= 4) return (long)cdiv(h, 4) * n_img * 9 * cin_w * cout + 64L * 9 * cin_w * cout;   // stem kernel slabs
+    if (kh == 2 && kw == 2) {                                // transposed: the split-operand TN plan (up to 512 / tiles splits) or the tile plan below
+        const long P = (long)n_img * h * w_;
+        const long tiles = (long)cdiv(cin_w, 128) * cdiv(cout, 128) * 4;
+        long splits = cdiv(512, tiles);
+        const long maxs = P / 256 > 0 ? P / 256 : 1;
+        if (splits > maxs) splits = maxs;
+        const long x3 = (long)cdiv(P, (cdiv(P, splits) + 15) / 16 * 16) * 4 * cin_w * cout;
+        TilePlan p = wgrad_tile_plan(n_img, h, w_, cin_w, cout, 1);
+        p.splits = cdiv(p.splits, 4); p.tps = cdiv(p.total_tiles, p.splits); p.splits = cdiv(p.total_tiles, p.tps);
+        bool big; int tl, sp;
+        wgrad_plan(P, cin_w, cout, 4, big, tl, sp);
+        const long a = p.splits > 1 ? (long)p.splits * 4 * cin_w * cout : 0;
+        const long b = sp > 1 ? (long)sp * 4 * cin_w * cout : 0;
+        const long m = a > b ? a : b;
+        return x3 > m ? x3 : m;
+    }
     if (kh == kw && (kh == 1 || kh == 3 || kh == 2)) {       // dilation unknown here: take the larger of the two plans
         TilePlan p = wgrad_tile_plan(n_img, h, w_, cin_w, cout, kh == 2 ? 1 : kh);
         if (kh == 2) { p.splits = cdiv(p.splits, 4); p.tps = cdiv(p.total_tiles, p.splits); p.splits = cdiv(p.total_tiles, p.tps); }
@@ -1038,6 +1062,23 @@ extern "C" int runet_conv_wgrad(const float* x, int ldx, const float* dy, int ld
         if (rc) return rc;
         if (splits > 1) hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(wsize, 32 * 4)), dim3(256), 0, st, workspace, dw, wsize, splits);
         RUNET_CHECK_LAUNCH();
+    }
+    if (transposed && cin_w == cin && convt_wgrad_x3((long)n_img * h * w_, w_, cin, cout)) {
+        // ConvTranspose2d weight gradient on the split-operand TN GEMM (gemm_split.hip): 4 taps = 4 GEMMs over the low-resolution pixels
+        const long P = (long)n_img * h * w_;
+        const long tiles = (long)cdiv(cin, 128) * cdiv(cout, 128) * 4;
+        long splits = cdiv(512, tiles);
+        const long maxs = P / 256 > 0 ? P / 256 : 1;
+        if (splits > maxs) splits = maxs;
+        const int rps = (int)((cdiv(P, splits) + 15) / 16 * 16);
+        const int ns = cdiv(P, rps);
+        const long wsize = 4L * cin * cout;
+        if (ns == 1 || (workspace && workspace_floats >= ns * wsize)) {
+            const int rc = runet_gemm_x3_tn_convt(x, ldx, dy, ldy, ns > 1 ? workspace : dw, n_img, h, w_, cin, cout, rps, stream);
+            if (rc) return rc;
+            if (ns > 1) hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(wsize, 32 * 4)), dim3(256), 0, st, workspace, dw, wsize, ns);
+            RUNET_CHECK_LAUNCH();
+        }
     }
     if (use_tile_kernel(kh, kw, dil, transposed)) {
         TilePlan p = wgrad_tile_plan(n_img, h, w_, cin_w, cout, transposed ? 1 : kh);

@@ -38,6 +38,7 @@ struct X3Args {
     int rows, k, n;
     int rps;                                  // TN: rows per split (multiple of 16)
     int gm, gn, gz;                           // tile grid (row tiles, column tiles, batch)
+    int cw;                                   // TN, transposed-convolution form: width W of the low-resolution image (rows = its pixels); B = dy [.., 2H, 2W, n]
 };
 
 // ------------------------------------------------------------------------------------------------------------------ NN
@@ -212,6 +213,11 @@ __device__ __forceinline__ bf16x8 tr_frag8(const unsigned char* plane, int col0,
     return u.b;
 }
 
+// CONVT: the weight gradient of ConvTranspose2d(k2, s2) - dW[a][b][ci][co] = sum over low-resolution pixels p of x[p][ci] * dy[(2h + a, 2w + b)][co].
+// z = tap (a, b); A rows are the low-resolution pixels as they lie in memory; the B row of pixel (img, h, w) is the high-resolution pixel
+// ((img * H + h) * 2 + a) * 2W + 2w + b.  W is a multiple of 16 (host check), so the 16 rows of a k-step share (img, h): their B rows are 2 pixels
+// apart from a per-step base that advances by 32 pixels, plus 2W more (the skipped odd / even row) when the step wraps to the next image row.
+template <bool CONVT>
 __global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(X3Args g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -225,8 +231,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(X3Args g) {
     const int kt = (int)(id % g.gm);
     const int z = (int)(id / g.gm);
     const int k0 = kt * 128, n0 = nt * 128;
-    const float* A = g.a + (long)z * g.sa;
-    const float* B = reinterpret_cast<const float*>(g.b) + (long)z * g.sb;
+    const float* A = g.a + (CONVT ? 0L : (long)z * g.sa);
+    const float* B = reinterpret_cast<const float*>(g.b) + (CONVT ? 0L : (long)z * g.sb);
     const int t_begin = blockIdx.y * g.rps;
     const int t_end = min(g.rows, t_begin + g.rps);
     const int nks = (t_end - t_begin) >> 4;            // whole 16-row tiles (host check)
@@ -235,13 +241,31 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(X3Args g) {
     const int q4 = (tid & 31) * 4;
     const int acol = k0 + q4 < g.k ? k0 + q4 : g.k - 4, bcol = n0 + q4 < g.n ? n0 + q4 : g.n - 4;
     struct Raw { f32x4 ra[2], rb[2]; };
+    // CONVT: base offset (elements) of the NEXT step's B rows and its column in the image row; steps are requested strictly in order
+    long cv_boff = 0;
+    int cv_w0 = 0, cv_ks = 0;
+    if constexpr (CONVT) {
+        const int R0 = t_begin / g.cw;
+        cv_w0 = t_begin - R0 * g.cw;
+        cv_boff = ((long)(2 * R0 + (z >> 1)) * (2 * g.cw) + 2 * cv_w0 + (z & 1)) * g.ldb;
+    }
     auto load_tile = [&](int ks, Raw& R) {
         const int kc = ks < nks ? ks : nks - 1;
 #pragma unroll
         for (int v = 0; v < 2; ++v) {
-            const long tr = t_begin + kc * 16 + (tid >> 5) + 8 * v;
+            const int rr = (tid >> 5) + 8 * v;
+            const long tr = t_begin + kc * 16 + rr;
             R.ra[v] = *reinterpret_cast<const f32x4*>(A + tr * g.lda + acol);
-            R.rb[v] = *reinterpret_cast<const f32x4*>(B + tr * g.ldb + bcol);
+            if constexpr (CONVT) R.rb[v] = *reinterpret_cast<const f32x4*>(B + cv_boff + (long)(2 * rr) * g.ldb + bcol);
+            else R.rb[v] = *reinterpret_cast<const f32x4*>(B + tr * g.ldb + bcol);
+        }
+        if constexpr (CONVT) {
+            if (cv_ks + 1 < nks) {                     // past the end the last step is read again
+                ++cv_ks;
+                cv_w0 += 16;
+                cv_boff += 32L * g.ldb;
+                if (cv_w0 >= g.cw) { cv_w0 = 0; cv_boff += 2L * g.cw * g.ldb; }
+            }
         }
     };
     int st_off[2];
@@ -423,6 +447,25 @@ extern "C" int runet_gemm_x3_tn_batched(const float* a, int lda, long stride_a, 
     g.gm = cdiv(k, 128); g.gn = cdiv(n, 128); g.gz = batch;
     const long total = (long)g.gm * g.gn * g.gz;
     RUNET_REQUIRE(total < (1L << 31), "grid too large");
-    hipLaunchKernelGGL(gemm_tn_x3_kernel, dim3((unsigned)total, splits), dim3(256), 3 * TN_STAGE_B, (hipStream_t)stream, g);
+    hipLaunchKernelGGL(gemm_tn_x3_kernel<false>, dim3((unsigned)total, splits), dim3(256), 3 * TN_STAGE_B, (hipStream_t)stream, g);
+    RUNET_CHECK_LAUNCH();
+}
+
+// Weight gradient of ConvTranspose2d(k2, s2) (Main_Final.py:261-270) on the split-operand TN GEMM: x [n_img, h, w, cin] (row stride ldx), dy
+// [n_img, 2h, 2w, cout] (ldy) -> c [splits][4 taps][cin][cout], splits = ceil(n_img h w / rows_per_split); w a multiple of 16.
+extern "C" int runet_gemm_x3_tn_convt(const float* x, int ldx, const float* dy, int ldy, float* c, int n_img, int h, int w, int cin, int cout,
+                                      int rows_per_split, void* stream) {
+    const long rows = (long)n_img * h * w;
+    RUNET_REQUIRE(x && dy && c && n_img > 0 && h > 0 && w > 0 && w % 16 == 0 && rows < (1L << 31) && rows_per_split > 0 && rows_per_split % 16 == 0,
+                  "bad arguments (w and rows_per_split: multiples of 16)");
+    RUNET_REQUIRE(cin >= 4 && cin % 4 == 0 && cout >= 4 && cout % 4 == 0 && ldx >= cin && ldx % 4 == 0 && ldy >= cout && ldy % 4 == 0, "channel counts and strides must be multiples of 4");
+    RUNET_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0, "alignment");
+    const int splits = cdiv(rows, rows_per_split);
+    RUNET_REQUIRE(splits <= 65535, "too many splits");
+    X3Args g{};
+    g.a = x; g.lda = ldx; g.b = dy; g.ldb = ldy; g.c = c; g.rows = (int)rows; g.k = cin; g.n = cout; g.rps = rows_per_split; g.cw = w;
+    g.gm = cdiv(cin, 128); g.gn = cdiv(cout, 128); g.gz = 4;
+    const long total = (long)g.gm * g.gn * g.gz;
+    hipLaunchKernelGGL(gemm_tn_x3_kernel<true>, dim3((unsigned)total, splits), dim3(256), 3 * TN_STAGE_B, (hipStream_t)stream, g);
     RUNET_CHECK_LAUNCH();
 }

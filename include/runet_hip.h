@@ -248,6 +248,10 @@ int runet_gemm_x3_batched(const float* a, int lda, long stride_a, const void* pa
 int runet_gemm_x3_tn_batched(const float* a, int lda, long stride_a, const float* b, int ldb, long stride_b, float* c, int batch, int rows, int k,
                              int n, int rows_per_split, void* stream);
 const char* runet_gemm_x3_kernel_name(int batch, int rows, int k, int n);
+/* weight gradient of ConvTranspose2d(k2, s2) (Main_Final.py:261-270) on the same TN kernel: x [n_img,h,w,cin], dy [n_img,2h,2w,cout] ->
+ * c [splits][2][2][cin][cout] (sum the splits in order: runet_conv_wgrad does); w % 16 == 0, rows_per_split % 16 == 0 */
+int runet_gemm_x3_tn_convt(const float* x, int ldx, const float* dy, int ldy, float* c, int n_img, int h, int w, int cin, int cout,
+                           int rows_per_split, void* stream);
 
 /* ---- nn.Conv2d(k=1) (Main_Final.py:126,131,172,205) and nn.ConvTranspose2d(k=2, s=2) (:261-270), forward and data gradient, by the same
  * split-operand scheme (csrc/conv_x3.hip): same modes and argument meaning as runet_conv_igemm (RUNET_CONV_FWD, RUNET_CONV_DGRAD,

@@ -404,3 +404,24 @@ def test_epilogue_statistics_equal_the_separate_pass(n, h, w, ci, co, k, monkeyp
     assert int(bn_a.nbt) == 1 and int(bn_b.nbt) == 1
     # the convolution's own result is unchanged by asking for statistics
     assert torch.equal(y, ops.conv_fwd(x, wt, b))
+
+
+@pytest.mark.parametrize("n,h,w,ci,co", [(2, 16, 16, 128, 64), (1, 16, 32, 256, 128), (2, 32, 48, 64, 64), (3, 8, 16, 192, 96)])
+def test_transposed_conv_weight_gradient_on_the_split_operand_gemm(n, h, w, ci, co):
+    """ConvTranspose2d(k2, s2) weight gradient (Main_Final.py:261-270) through runet_conv_wgrad's split-operand TN route (image width a multiple
+    of 16, both channel counts >= 64) against float64 torch: 2e-5 of the gradient's scale, also from the right half of a concat buffer."""
+    ops = _ops()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(n + h + w + ci)
+    x = torch.randn(n, ci, h, w, generator=g, dtype=torch.float64)
+    wt = (torch.randn(ci, co, 2, 2, generator=g, dtype=torch.float64) / ci ** 0.5).requires_grad_(True)
+    y = F.conv_transpose2d(x, wt, None, stride=2)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    ref = wt.grad.permute(2, 3, 0, 1)                       # [2, 2, ci, co]
+    xd = x.float().permute(0, 2, 3, 1).contiguous().to(dev)
+    dcat = torch.zeros(n, 2 * h, 2 * w, 2 * co, device=dev)
+    dcat[..., co:] = dy.float().permute(0, 2, 3, 1).to(dev)
+    got = ops.convt_wgrad(xd, dcat[..., co:])
+    err = float((got.double().cpu() - ref).abs().max() / ref.abs().max())
+    assert err <= 2e-5, err
