@@ -1,5 +1,8 @@
+"""Run-to-run determinism of the DeepLabV3+ train step at the benchmarked size (16 x 256^2): three steps from the same state, every gradient
+tensor compared bitwise; prints the tensors that differ.  (Found the LDS float atomics of head3x3_bwd_kernel in round 3.)"""
 import importlib, sys, torch
-sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pkg = importlib.import_module("eusipco-2026-robust-unet_amd")
 dl = importlib.import_module("oracle.deeplab_ref")
 DEV="cuda:0"
