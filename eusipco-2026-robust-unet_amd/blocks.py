@@ -230,6 +230,7 @@ def bn_backward(dy, x, mean, invstd, scale, sums, act=None, mask=None, out=None,
 
 
 CHAN_SUM_ON_SIDE = os.environ.get("RUNET_CHAN_SUM_MAIN", "0") != "1"
+FUSED_GATE_BN_SUMS = os.environ.get("RUNET_NO_FUSED_GATE_BN_SUMS", "0") != "1"      # the attention gates' BatchNorm-backward sums taken in ag_bwd2
 
 
 def chan_sum(x, out):
@@ -616,6 +617,25 @@ def gate_backward(gc, up, skip, p: UpGateParams, datt, dup, sink, pre=""):
     sync, tr = gc["sync"], gc["training"]
     ds = bn_backward(dsbn, gc["s"], gc["mean_p"], gc["invstd_p"], gc["sp"], sums_p, out=dsbn, sync=sync, training=tr)
     dpre = ops.empty_nhwc(n, h, w, f, skip)
+    fused_sums = FUSED_GATE_BN_SUMS and not (sync is not None and tr)
+    if fused_sums:
+        # the gate's two BatchNorm-backward reductions ride in the kernel that produces their incoming gradient
+        ws = scratch(lib.runet_ag_bwd2_bn_workspace_floats(P, f), dev)
+        check(lib.runet_ag_bwd2_bn(ds.data_ptr(), gc["g1"].data_ptr(), ops.ld(gc["g1"]), gc["x1"].data_ptr(), ops.ld(gc["x1"]), gc["sg"].data_ptr(),
+                                   gc["hg"].data_ptr(), gc["sx"].data_ptr(), gc["hx"].data_ptr(), p.wpsi.data_ptr(), gc["mean_g"].data_ptr(),
+                                   gc["invstd_g"].data_ptr(), gc["mean_x"].data_ptr(), gc["invstd_x"].data_ptr(), dpre.data_ptr(), ops.ld(dpre),
+                                   ws.data_ptr(), ws.numel(), dwpsi_db.data_ptr(), sums_g.data_ptr(), sums_x.data_ptr(), P, f, st))
+        use_g, use_x = (sums_g, sums_x) if tr else (zeros(2 * f, dev), zeros(2 * f, dev))
+        dg1 = bn_bwd_apply(dpre, gc["g1"], gc["mean_g"], gc["invstd_g"], gc["sg"], use_g, 0)
+        ops.conv_wgrad(up, dg1, 1, 1, out=wg_b[:cg * f])
+        chan_sum(dg1, wg_b[cg * f:])
+        ops.conv_dgrad(dg1, p.wg, out=dup, accumulate=True)
+        del dg1
+        dx1 = bn_bwd_apply(dpre, gc["x1"], gc["mean_x"], gc["invstd_x"], gc["sx"], use_x, 0, out=dpre)
+        ops.conv_wgrad(skip, dx1, 1, 1, out=wx_b[:c * f])
+        chan_sum(dx1, wx_b[c * f:])
+        ops.conv_dgrad(dx1, p.wx, out=dskip, accumulate=True)
+        return dskip
     ws = _ws(n, h * w, f, dev)
     check(lib.runet_ag_bwd2(ds.data_ptr(), gc["g1"].data_ptr(), ops.ld(gc["g1"]), gc["x1"].data_ptr(), ops.ld(gc["x1"]), gc["sg"].data_ptr(),
                             gc["hg"].data_ptr(), gc["sx"].data_ptr(), gc["hx"].data_ptr(), p.wpsi.data_ptr(), dpre.data_ptr(), ops.ld(dpre),

@@ -520,22 +520,34 @@ __global__ __launch_bounds__(TPB) void ag_bwd1_kernel(const float* __restrict__ 
     }
 }
 // dpre[p][f] = ds[p]*wpsi[f]*(pre>0) (written);  partial sums: dwpsi[f] = sum ds*relu(pre), dbpsi = sum ds
+// BN: also the local BatchNorm-backward sums of BOTH branches (W_g.1 and W_x.1 see the same incoming gradient dpre): columns
+// [F+1, 2F+1) sum dpre * ghat, [2F+1, 3F+1) sum dpre (dbeta of both), [3F+1, 4F+1) sum dpre * xhat - the values are in registers here, so the
+// two bn_bwd_reduce passes over (dpre, g1) and (dpre, x1) that used to follow are not needed.
+template <bool BN>
 __global__ __launch_bounds__(TPB) void ag_bwd2_partial(const float* __restrict__ ds, const float* __restrict__ g1, int ldg,
                                                        const float* __restrict__ x1, int ldx, const float* __restrict__ sg,
                                                        const float* __restrict__ hg, const float* __restrict__ sx,
                                                        const float* __restrict__ hx, const float* __restrict__ wpsi,
                                                        float* __restrict__ dpre, int ldp, long P, int F, long pix_per_chunk,
-                                                       float* __restrict__ part) {
+                                                       float* __restrict__ part, const float* __restrict__ mean_g,
+                                                       const float* __restrict__ invstd_g, const float* __restrict__ mean_x,
+                                                       const float* __restrict__ invstd_x) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int NC = BN ? 4 * F + 1 : F + 1;
     const int cvec = F / 4, rows = TPB / cvec, tid = threadIdx.x;
     const int col = tid % cvec, row = tid / cvec;
     const long p0 = (long)blockIdx.x * pix_per_chunk;
     const long p1 = p0 + pix_per_chunk < P ? p0 + pix_per_chunk : P;
     float sw[4] = {0, 0, 0, 0}, sb = 0.f;
+    float so[4] = {0, 0, 0, 0}, sog[4] = {0, 0, 0, 0}, sox[4] = {0, 0, 0, 0};
     if (row < rows) {
-        float a_g[4], b_g[4], a_x[4], b_x[4], wp[4];
+        float a_g[4], b_g[4], a_x[4], b_x[4], wp[4], mg[4], ig[4], mx[4], ix[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { const int f = col * 4 + q; a_g[q] = sg[f]; b_g[q] = hg[f]; a_x[q] = sx[f]; b_x[q] = hx[f]; wp[q] = wpsi[f]; }
+        for (int q = 0; q < 4; ++q) {
+            const int f = col * 4 + q;
+            a_g[q] = sg[f]; b_g[q] = hg[f]; a_x[q] = sx[f]; b_x[q] = hx[f]; wp[q] = wpsi[f];
+            if constexpr (BN) { mg[q] = mean_g[f]; ig[q] = invstd_g[f]; mx[q] = mean_x[f]; ix[q] = invstd_x[f]; }
+        }
         for (long p = p0 + row; p < p1; p += rows) {
             const f32x4 a = *reinterpret_cast<const f32x4*>(g1 + p * ldg + col * 4);
             const f32x4 b = *reinterpret_cast<const f32x4*>(x1 + p * ldx + col * 4);
@@ -546,19 +558,49 @@ __global__ __launch_bounds__(TPB) void ag_bwd2_partial(const float* __restrict__
                 const float pre = a[q] * a_g[q] + b_g[q] + b[q] * a_x[q] + b_x[q];
                 o[q] = pre > 0.f ? d * wp[q] : 0.f;
                 sw[q] += d * fmaxf(pre, 0.f);
+                if constexpr (BN) {
+                    so[q] += o[q];
+                    sog[q] += o[q] * ((a[q] - mg[q]) * ig[q]);
+                    sox[q] += o[q] * ((b[q] - mx[q]) * ix[q]);
+                }
             }
             if (col == 0) sb += d;
             *reinterpret_cast<f32x4*>(dpre + p * ldp + col * 4) = o;
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) sm[row * (F + 1) + col * 4 + q] = sw[q];
-        if (col == 0) sm[row * (F + 1) + F] = sb;
+        for (int q = 0; q < 4; ++q) {
+            sm[row * NC + col * 4 + q] = sw[q];
+            if constexpr (BN) {
+                sm[row * NC + F + 1 + col * 4 + q] = sog[q];
+                sm[row * NC + 2 * F + 1 + col * 4 + q] = so[q];
+                sm[row * NC + 3 * F + 1 + col * 4 + q] = sox[q];
+            }
+        }
+        if (col == 0) sm[row * NC + F] = sb;
     }
     __syncthreads();
-    for (int c = tid; c < F + 1; c += TPB) {
+    for (int c = tid; c < NC; c += TPB) {
         double a = 0;
-        for (int r = 0; r < rows; ++r) a += sm[r * (F + 1) + c];
-        part[(long)blockIdx.x * (F + 1) + c] = (float)a;
+        for (int r = 0; r < rows; ++r) a += sm[r * NC + c];
+        part[(long)blockIdx.x * NC + c] = (float)a;
+    }
+}
+// column sums of ag_bwd2_partial<true>'s partials to their three destinations: (dwpsi | dbpsi), W_g.1's (dgamma | dbeta), W_x.1's (dgamma | dbeta)
+__global__ void ag_bwd2_bn_final(const float* __restrict__ part, long nrows, int F, float* __restrict__ dwpsi_db, float* __restrict__ sums_g,
+                                 float* __restrict__ sums_x) {
+    const int c = blockIdx.x, NC = 4 * F + 1;
+    double acc = 0;
+    for (long r = threadIdx.x; r < nrows; r += blockDim.x) acc += part[r * NC + c];
+    acc = wave_sum_d(acc);
+    __shared__ double red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float v = (float)(red[0] + red[1] + red[2] + red[3]);
+        if (c <= F) dwpsi_db[c] = v;
+        else if (c < 2 * F + 1) sums_g[c - (F + 1)] = v;                                  // dgamma of W_g.1
+        else if (c < 3 * F + 1) { sums_g[F + c - (2 * F + 1)] = v; sums_x[F + c - (2 * F + 1)] = v; }      // dbeta of both
+        else sums_x[c - (3 * F + 1)] = v;                                                 // dgamma of W_x.1
     }
 }
 
@@ -797,8 +839,37 @@ extern "C" int runet_ag_bwd2(const float* ds, const float* g1, int ldg, const fl
     chunking(pixels, f, chunks, ppc);
     const int rows = TPB / (f / 4);
     const size_t lds = (size_t)rows * (f + 1) * sizeof(float);
-    hipLaunchKernelGGL(ag_bwd2_partial, dim3((int)chunks), dim3(TPB), lds, st, ds, g1, ldg, x1, ldx, sg, hg, sx, hx, wpsi, dpre, ldp, pixels, f, ppc, workspace);
+    hipLaunchKernelGGL(ag_bwd2_partial<false>, dim3((int)chunks), dim3(TPB), lds, st, ds, g1, ldg, x1, ldx, sg, hg, sx, hx, wpsi, dpre, ldp, pixels, f, ppc,
+                       workspace, nullptr, nullptr, nullptr, nullptr);
     hipLaunchKernelGGL(reduce_rows_kernel, dim3(f + 1), dim3(256), 0, st, workspace, chunks, f + 1, dwpsi_db);
+    RUNET_CHECK_LAUNCH();
+}
+
+extern "C" long runet_ag_bwd2_bn_workspace_floats(long pixels, int f) {
+    long chunks, ppc;
+    chunking(pixels, f, chunks, ppc);
+    return chunks * (4L * f + 1) + 64;
+}
+
+// runet_ag_bwd2 that also leaves the local BatchNorm-backward sums of W_g.1 and W_x.1 (Main_Final.py:127,132) behind: sums_g / sums_x [2f] =
+// (sum dpre * xhat | sum dpre) as runet_bn_bwd_reduce would compute them from (dpre, g1) and (dpre, x1) - two passes over three tensors less.
+extern "C" int runet_ag_bwd2_bn(const float* ds, const float* g1, int ldg, const float* x1, int ldx, const float* sg, const float* hg,
+                                const float* sx, const float* hx, const float* wpsi, const float* mean_g, const float* invstd_g,
+                                const float* mean_x, const float* invstd_x, float* dpre, int ldp, float* workspace, long workspace_floats,
+                                float* dwpsi_db, float* sums_g, float* sums_x, long pixels, int f, void* stream) {
+    RUNET_REQUIRE(ds && g1 && x1 && sg && hg && sx && hx && wpsi && mean_g && invstd_g && mean_x && invstd_x && dpre && workspace && dwpsi_db &&
+                  sums_g && sums_x, "null pointer");
+    REQ_C4(f);
+    RUNET_REQUIRE(workspace_floats >= runet_ag_bwd2_bn_workspace_floats(pixels, f), "workspace too small (runet_ag_bwd2_bn_workspace_floats)");
+    hipStream_t st = (hipStream_t)stream;
+    long chunks, ppc;
+    chunking(pixels, f, chunks, ppc);
+    const int rows = TPB / (f / 4);
+    const size_t lds = (size_t)rows * (4 * f + 1) * sizeof(float);
+    RUNET_REQUIRE(lds <= 64 * 1024, "LDS budget");
+    hipLaunchKernelGGL(ag_bwd2_partial<true>, dim3((int)chunks), dim3(TPB), lds, st, ds, g1, ldg, x1, ldx, sg, hg, sx, hx, wpsi, dpre, ldp, pixels, f, ppc,
+                       workspace, mean_g, invstd_g, mean_x, invstd_x);
+    hipLaunchKernelGGL(ag_bwd2_bn_final, dim3(4 * f + 1), dim3(256), 0, st, workspace, chunks, f, dwpsi_db, sums_g, sums_x);
     RUNET_CHECK_LAUNCH();
 }
 

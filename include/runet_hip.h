@@ -181,6 +181,13 @@ int runet_ag_bwd1(const float* datt, int ldd, const float* xs, int ldx, const fl
 int runet_ag_bwd2(const float* ds, const float* g1, int ldg, const float* x1, int ldx, const float* sg, const float* hg, const float* sx,
                   const float* hx, const float* wpsi, float* dpre, int ldp, float* workspace, float* dwpsi_db, long pixels, int f,
                   void* stream);
+/* runet_ag_bwd2 that also leaves the LOCAL BatchNorm-backward sums of the gate's two BatchNorms (W_g.1, W_x.1: Main_Final.py:127,132) behind -
+ * sums_g / sums_x [2f] = (sum dpre * xhat | sum dpre), what runet_bn_bwd_reduce would compute from (dpre, g1) and (dpre, x1) */
+long runet_ag_bwd2_bn_workspace_floats(long pixels, int f);
+int runet_ag_bwd2_bn(const float* ds, const float* g1, int ldg, const float* x1, int ldx, const float* sg, const float* hg, const float* sx,
+                     const float* hx, const float* wpsi, const float* mean_g, const float* invstd_g, const float* mean_x, const float* invstd_x,
+                     float* dpre, int ldp, float* workspace, long workspace_floats, float* dwpsi_db, float* sums_g, float* sums_x, long pixels, int f,
+                     void* stream);
 
 /* ---- outc: Conv2d(C, 1, 1) + Sigmoid (Main_Final.py:274-277) ---- */
 int runet_outc_fwd(const float* x, int ld, const float* w, const float* b, float* logit, float* prob, long pixels, int c, void* stream);

@@ -189,7 +189,7 @@ def hip_step(model, x, y, dev=None):
     blocks = importlib.import_module(PKG_NAME + ".blocks")
     dev = dev or next(model.parameters()).device
     dec = {"gate": {}, "pool": {}, "sa": {}, "ca": {}, "act": {}}
-    real_back, real_bn = model_mod.net_backward, blocks.bn_backward
+    real_back, real_bn, real_apply = model_mod.net_backward, blocks.bn_backward, blocks.bn_bwd_apply
     gate_g1 = {}
 
     def nchw(t):
@@ -214,12 +214,18 @@ def hip_step(model, x, y, dev=None):
                 dec["gate"][name] = nchw(dy) != 0
         return real_bn(dy, xx, *a, **k)
 
-    model_mod.net_backward, blocks.bn_backward = spy, bn_spy
+    def apply_spy(dy, xx, *a, **k):       # the fused path (ag_bwd2 carries the BatchNorm sums) goes straight to bn_bwd_apply: same dy, same g1
+        for name, g1 in gate_g1.items():
+            if xx is g1 and name not in dec["gate"]:
+                dec["gate"][name] = nchw(dy) != 0
+        return real_apply(dy, xx, *a, **k)
+
+    model_mod.net_backward, blocks.bn_backward, blocks.bn_bwd_apply = spy, bn_spy, apply_spy
     try:
         prob, logit = model(x.to(dev), return_logits=True)
         pkg.bce_loss(prob, y.to(dev)).backward()
     finally:
-        model_mod.net_backward, blocks.bn_backward = real_back, real_bn
+        model_mod.net_backward, blocks.bn_backward, blocks.bn_bwd_apply = real_back, real_bn, real_apply
     torch.cuda.synchronize()
     dec["prob"] = prob.detach().cpu()
     return dec, prob.detach().cpu(), logit.detach().cpu()
