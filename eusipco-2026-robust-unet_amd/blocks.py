@@ -230,6 +230,10 @@ def bn_backward(dy, x, mean, invstd, scale, sums, act=None, mask=None, out=None,
 
 
 CHAN_SUM_ON_SIDE = os.environ.get("RUNET_CHAN_SUM_MAIN", "0") != "1"
+# the shortcut BatchNorm's backward sums taken in rb_bwd2 (runet_rb_bwd2_bn) instead of by bn_bwd_reduce(dv, r): one tensor read and one launch
+# less per block, but measured SLOWER in the step (A/B 545.0 vs 540.5 img/s: the reduction kernel gets twice the LDS and registers, the pass it
+# replaces ran at HBM speed) - opt-in (RUNET_FUSED_SHORTCUT_BN_SUMS=1), kept equal by tests/test_gpu_blocks.py
+FUSED_SHORTCUT_BN_SUMS = os.environ.get("RUNET_FUSED_SHORTCUT_BN_SUMS", "0") == "1"
 FUSED_GATE_BN_SUMS = os.environ.get("RUNET_NO_FUSED_GATE_BN_SUMS", "0") != "1"      # the attention gates' BatchNorm-backward sums taken in ag_bwd2
 
 
@@ -341,9 +345,19 @@ def rb_backward(ctx, dout, sink, pre="", need_dx=True):
     ws = scratch(lib.runet_sa_conv7_bwd_workspace_floats(n, h, w), dev)
     check(lib.runet_sa_conv7_bwd(smap.data_ptr(), dq.data_ptr(), p.wsa.data_ptr(), dsm.data_ptr(), dwsa.data_ptr(), ws.data_ptr(), n, h, w, st))
     sdu, sdut = sm.f(n * c), sm.f(n * c)
-    ws = _ws(n, hw, c, dev)
-    check(lib.runet_rb_bwd2(dv.data_ptr(), ops.ld(dv), t2.data_ptr(), ops.ld(t2), sa.data_ptr(), dsm.data_ptr(), amax.data_ptr(), n, hw, c,
-                            ws.data_ptr(), sdu.data_ptr(), sdut.data_ptr(), st))
+    sync, tr = ctx["sync"], ctx["training"]
+    sums_s_fused = None
+    if p.ws is not None and FUSED_SHORTCUT_BN_SUMS and not (sync is not None and tr):
+        # dv is the shortcut BatchNorm's incoming gradient: its backward reduction rides in this pass (one read of r instead of a pass over dv and r)
+        sums_s_fused = sink.buf(pre, [("shortcut.1.weight", (c,)), ("shortcut.1.bias", (c,))])
+        ws = scratch(lib.runet_rb_bwd2_bn_workspace_floats(n, hw, c), dev)
+        check(lib.runet_rb_bwd2_bn(dv.data_ptr(), ops.ld(dv), t2.data_ptr(), ops.ld(t2), sa.data_ptr(), dsm.data_ptr(), amax.data_ptr(), r.data_ptr(),
+                                   ops.ld(r), ctx["mean_s"].data_ptr(), ctx["invstd_s"].data_ptr(), n, hw, c, ws.data_ptr(), ws.numel(),
+                                   sdu.data_ptr(), sdut.data_ptr(), sums_s_fused.data_ptr(), st))
+    else:
+        ws = _ws(n, hw, c, dev)
+        check(lib.runet_rb_bwd2(dv.data_ptr(), ops.ld(dv), t2.data_ptr(), ops.ld(t2), sa.data_ptr(), dsm.data_ptr(), amax.data_ptr(), n, hw, c,
+                                ws.data_ptr(), sdu.data_ptr(), sdut.data_ptr(), st))
     davg, dmx = sm.f(n * c), sm.f(n * c)
     sums2 = sink.buf(pre, [("bn2.weight", (c,)), ("bn2.bias", (c,))])
     dw0p = sink.buf(pre, [("ca.fc.0.weight", (1, 1, c, cr))])
@@ -354,7 +368,6 @@ def rb_backward(ctx, dout, sink, pre="", need_dx=True):
                            ctx["tval"].data_ptr(), ctx["mean2"].data_ptr(), ctx["invstd2"].data_ptr(), n, c, cr, ws.data_ptr(),
                            davg.data_ptr(), dmx.data_ptr(), sums2.data_ptr(), dw0p.data_ptr(), dw2p.data_ptr(), st))
     dt2 = ops.empty_nhwc(n, h, w, c, x)
-    sync, tr = ctx["sync"], ctx["training"]
     use_s = None
     if not tr:
         use2, m_total = zeros(2 * c, dev), 0
@@ -389,6 +402,8 @@ def rb_backward(ctx, dout, sink, pre="", need_dx=True):
     if p.ws is not None:
         if use_s is not None:
             dr = bn_bwd_apply(dv, r, ctx["mean_s"], ctx["invstd_s"], ctx["ss"], use_s, m_s, out=dv)
+        elif sums_s_fused is not None:
+            dr = bn_bwd_apply(dv, r, ctx["mean_s"], ctx["invstd_s"], ctx["ss"], sums_s_fused if tr else zeros(2 * c, dev), 0, out=dv)
         else:
             sums_s = sink.buf(pre, [("shortcut.1.weight", (c,)), ("shortcut.1.bias", (c,))])
             dr = bn_backward(dv, r, ctx["mean_s"], ctx["invstd_s"], ctx["ss"], sums_s, out=dv, sync=sync, training=tr)

@@ -284,22 +284,34 @@ __global__ void reduce_rows_kernel(const float* __restrict__ part, long nrows, i
 }
 
 // ---- backward 2: per-(n,c) sums of du and du*t2;  du = dv*sa + dsm0/C + dsm1*[c == amax]
+// BN: also the shortcut BatchNorm's local backward sums - dv IS that BatchNorm's incoming gradient: per (n, chunk, c) sum dv and
+// sum dv * rhat (rhat = (r - mean_s) * invstd_s), so the bn_bwd_reduce pass over (dv, r) that used to follow is one read of r here.
+template <bool BN>
 __global__ __launch_bounds__(TPB) void rb_bwd2_partial(const float* __restrict__ dv, int lddv, const float* __restrict__ t2, int ld,
                                                        const float* __restrict__ sa, const float* __restrict__ dsm,
                                                        const int* __restrict__ amax, int HW, int C, int pix_per_chunk,
-                                                       float* __restrict__ part) {
+                                                       float* __restrict__ part, const float* __restrict__ r, int ldr,
+                                                       const float* __restrict__ mean_s, const float* __restrict__ invstd_s) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int NV = BN ? 4 : 2;
     const int cvec = C / 4, rows = TPB / cvec, tid = threadIdx.x;
     const int col = tid % cvec, row = tid / cvec;
     const int n = blockIdx.y, chunk = blockIdx.x;
     const int p0 = chunk * pix_per_chunk, p1 = min(HW, p0 + pix_per_chunk);
-    float s[4] = {0, 0, 0, 0}, st[4] = {0, 0, 0, 0};
+    float s[4] = {0, 0, 0, 0}, st[4] = {0, 0, 0, 0}, sv[4] = {0, 0, 0, 0}, svr[4] = {0, 0, 0, 0};
     const float invC = 1.0f / (float)C;
     if (row < rows) {
+        float ms[4], is[4];
+        if constexpr (BN) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { ms[q] = mean_s[col * 4 + q]; is[q] = invstd_s[col * 4 + q]; }
+        }
         const long ib = (long)n * HW;
         for (int p = p0 + row; p < p1; p += rows) {
             const f32x4 d = *reinterpret_cast<const f32x4*>(dv + (ib + p) * lddv + col * 4);
             const f32x4 t = *reinterpret_cast<const f32x4*>(t2 + (ib + p) * ld + col * 4);
+            f32x4 rr = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (BN) rr = *reinterpret_cast<const f32x4*>(r + (ib + p) * ldr + col * 4);
             const float v = sa[ib + p], g0 = dsm[(ib + p) * 2] * invC, g1 = dsm[(ib + p) * 2 + 1];
             const int am = amax[ib + p];
 #pragma unroll
@@ -307,29 +319,53 @@ __global__ __launch_bounds__(TPB) void rb_bwd2_partial(const float* __restrict__
                 const float du = d[q] * v + g0 + ((col * 4 + q) == am ? g1 : 0.f);
                 s[q] += du;
                 st[q] += du * t[q];
+                if constexpr (BN) { sv[q] += d[q]; svr[q] += d[q] * ((rr[q] - ms[q]) * is[q]); }
             }
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { sm[(row * C + col * 4 + q) * 2] = s[q]; sm[(row * C + col * 4 + q) * 2 + 1] = st[q]; }
+        for (int q = 0; q < 4; ++q) {
+            float* o = sm + (row * C + col * 4 + q) * NV;
+            o[0] = s[q]; o[1] = st[q];
+            if constexpr (BN) { o[2] = sv[q]; o[3] = svr[q]; }
+        }
     }
     __syncthreads();
     for (int c = tid; c < C; c += TPB) {
-        double a = 0, b = 0;
-        for (int r = 0; r < rows; ++r) { a += sm[(r * C + c) * 2]; b += sm[(r * C + c) * 2 + 1]; }
-        float* o = part + (((long)n * gridDim.x + chunk) * C + c) * 2;
-        o[0] = (float)a; o[1] = (float)b;
+        double a[NV];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) a[j] = 0;
+        for (int rw = 0; rw < rows; ++rw)
+#pragma unroll
+            for (int j = 0; j < NV; ++j) a[j] += sm[(rw * C + c) * NV + j];
+        float* o = part + (((long)n * gridDim.x + chunk) * C + c) * NV;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) o[j] = (float)a[j];
     }
 }
-__global__ void rb_bwd2_final(const float* __restrict__ part, int N, int C, int nchunks, float* __restrict__ sdu, float* __restrict__ sdut) {
+__global__ void rb_bwd2_final(const float* __restrict__ part, int N, int C, int nchunks, int nv, float* __restrict__ sdu, float* __restrict__ sdut) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N * C) return;
     const int n = i / C, c = i - n * C;
     double a = 0, b = 0;
     for (int k = 0; k < nchunks; ++k) {
-        const float* o = part + (((long)n * nchunks + k) * C + c) * 2;
+        const float* o = part + (((long)n * nchunks + k) * C + c) * nv;
         a += o[0]; b += o[1];
     }
     sdu[i] = (float)a; sdut[i] = (float)b;
+}
+// the shortcut BatchNorm's (dgamma | dbeta) from the partials of rb_bwd2_partial<true>: one block per channel over all (image, chunk) rows
+__global__ void rb_bwd2_bn_final(const float* __restrict__ part, long nrows, int C, float* __restrict__ sums_s) {
+    const int c = blockIdx.x;
+    double a = 0, b = 0;
+    for (long rw = threadIdx.x; rw < nrows; rw += blockDim.x) { a += part[(rw * C + c) * 4 + 2]; b += part[(rw * C + c) * 4 + 3]; }
+    a = wave_sum_d(a); b = wave_sum_d(b);
+    __shared__ double red[2][4];
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        sums_s[C + c] = (float)(red[0][0] + red[0][1] + red[0][2] + red[0][3]);      // dbeta  = sum dv
+        sums_s[c] = (float)(red[1][0] + red[1][1] + red[1][2] + red[1][3]);          // dgamma = sum dv * rhat
+    }
 }
 
 // ---- channel-attention backward, phase 1, per image (grid N): dz, the MLP's hidden gradients, davg/dmx.
@@ -764,8 +800,44 @@ extern "C" int runet_rb_bwd2(const float* dv, int lddv, const float* t2, int ld,
     if (per_img < 1) per_img = 1;
     const int ppc = (int)((hw + per_img - 1) / per_img);
     const size_t lds = (size_t)rows * c * 2 * sizeof(float);
-    hipLaunchKernelGGL(rb_bwd2_partial, dim3((int)per_img, n_img), dim3(TPB), lds, st, dv, lddv, t2, ld, sa, dsm, amax, hw, c, ppc, workspace);
-    hipLaunchKernelGGL(rb_bwd2_final, dim3(cdiv((long)n_img * c, 128)), dim3(128), 0, st, workspace, n_img, c, (int)per_img, sdu, sdut);
+    hipLaunchKernelGGL(rb_bwd2_partial<false>, dim3((int)per_img, n_img), dim3(TPB), lds, st, dv, lddv, t2, ld, sa, dsm, amax, hw, c, ppc, workspace,
+                       nullptr, 0, nullptr, nullptr);
+    hipLaunchKernelGGL(rb_bwd2_final, dim3(cdiv((long)n_img * c, 128)), dim3(128), 0, st, workspace, n_img, c, (int)per_img, 2, sdu, sdut);
+    RUNET_CHECK_LAUNCH();
+}
+
+static long rb_bwd2_chunks(int hw, int c, int& ppc) {
+    const int rows = TPB / (c / 4);
+    long per_img = ((long)hw * c + 32767) / 32768;
+    if (per_img > 1024) per_img = 1024;
+    const long maxc = (hw + rows - 1) / rows;
+    if (per_img > maxc) per_img = maxc;
+    if (per_img < 1) per_img = 1;
+    ppc = (int)((hw + per_img - 1) / per_img);
+    return per_img;
+}
+extern "C" long runet_rb_bwd2_bn_workspace_floats(int n_img, int hw, int c) {
+    int ppc;
+    return (long)n_img * rb_bwd2_chunks(hw, c, ppc) * c * 4 + 64;
+}
+// runet_rb_bwd2 that also leaves the LOCAL BatchNorm-backward sums of the block's shortcut BatchNorm (Main_Final.py:173) behind: dv is that
+// BatchNorm's incoming gradient, r [n, hw, c] its input; sums_s [2c] = (sum dv * rhat | sum dv), what runet_bn_bwd_reduce(dv, r) computes.
+extern "C" int runet_rb_bwd2_bn(const float* dv, int lddv, const float* t2, int ld, const float* sa, const float* dsm, const int* amax, const float* r,
+                                int ldr, const float* mean_s, const float* invstd_s, int n_img, int hw, int c, float* workspace,
+                                long workspace_floats, float* sdu, float* sdut, float* sums_s, void* stream) {
+    RUNET_REQUIRE(dv && t2 && sa && dsm && amax && r && mean_s && invstd_s && workspace && sdu && sdut && sums_s, "null pointer");
+    REQ_C4(c);
+    RUNET_REQUIRE(ldr >= c && ldr % 4 == 0 && workspace_floats >= runet_rb_bwd2_bn_workspace_floats(n_img, hw, c), "bad stride / workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    int ppc;
+    const long per_img = rb_bwd2_chunks(hw, c, ppc);
+    const int rows = TPB / (c / 4);
+    const size_t lds = (size_t)rows * c * 4 * sizeof(float);
+    RUNET_REQUIRE(lds <= 64 * 1024, "LDS budget");
+    hipLaunchKernelGGL(rb_bwd2_partial<true>, dim3((int)per_img, n_img), dim3(TPB), lds, st, dv, lddv, t2, ld, sa, dsm, amax, hw, c, ppc, workspace, r, ldr,
+                       mean_s, invstd_s);
+    hipLaunchKernelGGL(rb_bwd2_final, dim3(cdiv((long)n_img * c, 128)), dim3(128), 0, st, workspace, n_img, c, (int)per_img, 4, sdu, sdut);
+    hipLaunchKernelGGL(rb_bwd2_bn_final, dim3(c), dim3(256), 0, st, workspace, (long)n_img * per_img, c, sums_s);
     RUNET_CHECK_LAUNCH();
 }
 

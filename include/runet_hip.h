@@ -162,6 +162,12 @@ int runet_sa_conv7_bwd(const float* smap, const float* dq, const float* wp, floa
                        int w, void* stream);
 int runet_rb_bwd2(const float* dv, int lddv, const float* t2, int ld, const float* sa, const float* dsm, const int* amax, int n_img,
                   int hw, int c, float* workspace, float* sdu, float* sdut, void* stream);
+/* runet_rb_bwd2 that also leaves the LOCAL BatchNorm-backward sums of the block's shortcut BatchNorm (Main_Final.py:173) behind: dv is that
+ * BatchNorm's incoming gradient and r its input; sums_s [2c] = (sum dv * rhat | sum dv), what runet_bn_bwd_reduce(dv, r) would compute */
+long runet_rb_bwd2_bn_workspace_floats(int n_img, int hw, int c);
+int runet_rb_bwd2_bn(const float* dv, int lddv, const float* t2, int ld, const float* sa, const float* dsm, const int* amax, const float* r, int ldr,
+                     const float* mean_s, const float* invstd_s, int n_img, int hw, int c, float* workspace, long workspace_floats, float* sdu,
+                     float* sdut, float* sums_s, void* stream);
 long runet_ca_bwd_workspace_floats(int n_img, int c, int cr);
 int runet_ca_bwd(const float* sdu, const float* sdut, const float* s2, const float* h2, const float* ca, const float* avg, const float* mx,
                  const float* w0p, const float* w2p, const float* mean_nc, const float* tval, const float* mean2, const float* invstd2,
