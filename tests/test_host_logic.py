@@ -140,3 +140,25 @@ def test_device_prefetcher_passthrough_on_cpu(pkg):
     out = list(pkg.DevicePrefetcher(batches, "cpu"))
     assert len(out) == 4 and all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(out, batches))
     assert list(pkg.DevicePrefetcher([], "cpu")) == []
+
+
+def test_split_operand_dispatch_policy():
+    """ops._conv_x3_case: which 1x1 / transposed launches take the split-operand kernel (contraction >= 256, or >= 128 with
+    >= 128 output channels; multiples of 16 / 4 channels; fp32 mode only) - pure host logic."""
+    import importlib
+
+    import torch
+    ops = importlib.import_module("eusipco-2026-robust-unet_amd.ops")
+
+    def case(cin, cout, taps=1, cin_w=None, ldx=None):
+        x = torch.empty(1, 2, 2, ldx or cin)[..., :cin]
+        return ops._conv_x3_case(x, cin, cin if cin_w is None else cin_w, cout, taps)
+    assert case(512, 256) and case(256, 32) and case(1024, 4)            # deep contraction: any width
+    assert case(128, 128) and case(128, 256) and not case(128, 64)       # 128-deep: wide outputs only
+    assert not case(64, 128) and not case(64, 32)                        # 64-deep launches stay on the implicit GEMM ...
+    assert case(64, 128, taps=4) and not case(32, 64, taps=4)            # ... unless four taps make the contraction 256 deep (transposed data gradient)
+    assert not case(264, 256) and not case(256, 30)                      # contraction a multiple of 16 channels, outputs of 4
+    assert not case(4, 64, cin_w=3)                                      # the RGB stem
+    with ops.precision("bf16"):
+        assert not case(512, 256)                                        # reduced-precision modes have their own kernels
+    assert case(512, 256)
