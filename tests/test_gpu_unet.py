@@ -176,3 +176,37 @@ def test_plain_unet_gradients_under_the_hip_decisions(pkg, n, size, seed, monkey
     print(f"\nplain U-Net {n} x {size}^2: {len(flips)} near-tie decisions forced; worst gradient errors / scale {[(f'{e:.1e}', k) for e, k in rows[:4]]}, median {np.median([r[0] for r in rows]):.1e}")
     assert rows[0][0] <= 5e-4, rows[:4]          # measured: 1.6e-4 at worst (a transposed convolution's bias: a sum over every pixel), 1e-5 typical
     assert float(np.median([r[0] for r in rows])) <= 3e-5
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+def test_plain_unet_reduced_precision_step_against_the_fp32_oracle(pkg, mode):
+    """set_precision("bf16" / "fp16") on the plain U-Net (operands of the matrix-core products rounded, everything else fp32), incl. its 64 -> 4
+    padded head through the packed-weight path: one train step against the fp32 oracle at the Robust U-Net's reduced-precision bands
+    (tests/test_gpu_bf16.py; the reference is fp32 only, so these bands are this repository's): logits within 2.5 % of their scale, loss
+    within 1 %, cosine of the full gradient >= 0.97."""
+    pu = _pu()
+    n, size, seed = 2, 64, 9
+    st = pu.init_state(3, 2, seed=seed, perturb_bn=True)
+    net = pkg.UNet(3, 2)
+    net.load_state_dict(st)
+    net = net.to(DEV).train().set_precision(mode)
+    x, y = pkg.synthetic_batch(n, size, seed=seed)
+    target = y[:, 0].long()
+    logits = net(x.to(DEV))
+    loss = pkg.cross_entropy(logits, target.to(DEV))
+    loss.backward()
+    names = pu.param_names(3, 2)
+    P = {k: v.clone() for k, v in st.items()}
+    for k in names:
+        P[k].requires_grad_(True)
+    ref = pu.forward(P, x, True)
+    rloss = pu.ce_mean(ref, target)
+    rloss.backward()
+    scale = float(ref.detach().abs().max())
+    assert float((logits.detach().cpu() - ref.detach()).abs().max()) <= 2.5e-2 * scale
+    assert abs(float(loss) - float(rloss)) <= 1e-2 * abs(float(rloss))
+    skip = {k for k in names if k.endswith(".bias") and k.split(".")[-2] in ("0", "3")}
+    g = torch.cat([p.grad.detach().cpu().double().reshape(-1) for k, p in net.named_parameters() if k not in skip])
+    r = torch.cat([P[k].grad.double().reshape(-1) for k in names if k not in skip])
+    cos = float((g @ r) / (g.norm() * r.norm()))
+    assert cos >= 0.97, cos
