@@ -317,7 +317,12 @@ USE_WINOGRAD4 = USE_WINOGRAD and os.environ.get("RUNET_NO_WINOGRAD4", "0") != "1
 USE_WINOGRAD4_DILATED = USE_WINOGRAD4 and os.environ.get("RUNET_NO_WINOGRAD4_DILATED", "0") != "1"
 
 
-WINO4_MIN_WIDE = int(os.environ.get("RUNET_WINO4_MIN_WIDE", "256"))      # channels the wider side needs for the unfused F(4x4) path
+# Channels the wider / narrower side needs and the largest image (pixels) for the unfused F(4x4) path.  128 / 128 since the data gradient
+# shares Z = A dy A^T with the weight gradient (adjoint form): before that, sending the 128 -> 128 @ 128^2 layers here cut 1.1 ms of kernel time
+# but added 4 GB of Winograd-domain traffic and did not move the step (533.0 vs 532.7 img/s); with it 538.2 -> 547.1 (three A/B pairs).
+WINO4_MIN_WIDE = int(os.environ.get("RUNET_WINO4_MIN_WIDE", "128"))
+WINO4_MIN_NARROW = int(os.environ.get("RUNET_WINO4_MIN_NARROW", "128"))
+WINO4_MAX_PIXELS = int(os.environ.get("RUNET_WINO4_MAX_PIXELS", str(128 * 128)))
 
 
 def _wino4_case(h, w, kh, dil, k, n, cin_w):
@@ -326,7 +331,7 @@ def _wino4_case(h, w, kh, dil, k, n, cin_w):
     the sub-images of every image (csrc/conv_winograd4.hip pix()): 4x fewer multiplies than the implicit GEMM they used before."""
     if dil != 1 and not (USE_WINOGRAD4_DILATED and h % dil == 0 and w % dil == 0):
         return False
-    return (USE_WINOGRAD4 and kh == 3 and cin_w == k and max(k, n) >= WINO4_MIN_WIDE and min(k, n) >= 128 and h * w <= 128 * 128
+    return (USE_WINOGRAD4 and kh == 3 and cin_w == k and max(k, n) >= WINO4_MIN_WIDE and min(k, n) >= WINO4_MIN_NARROW and h * w <= WINO4_MAX_PIXELS
             and bool(lib.runet_wino4_supported(h // dil, w // dil, k, n)))
 
 
