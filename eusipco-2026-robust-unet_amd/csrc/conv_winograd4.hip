@@ -15,6 +15,7 @@
 // Interpolation points 0, +-1, +-2, inf (Lavin & Gray); fp32 throughout, error ~1e-5 relative to the direct convolution.
 #include "runet_common.h"
 #include "../../include/runet_hip.h"
+#include "derive_weights.h"
 
 namespace {
 
@@ -275,61 +276,7 @@ typedef __bf16 w4_bf16x8 __attribute__((ext_vector_type(8)));
 // dgrad: 0 forward (K = cin);  1 rotated filter for the data gradient computed as a convolution (K = cout);  2 the forward's U TRANSPOSED over
 // (k, n) and not rotated, for the data gradient computed as the ADJOINT of the forward algorithm (K = cout; wino4_output_adj_kernel)
 __global__ __launch_bounds__(256) void wino4_weight_x3_kernel(const float* __restrict__ w, __bf16* __restrict__ Up, int cin, int cout, int dgrad) {
-    const int K = dgrad ? cout : cin, N = dgrad ? cin : cout;
-    const int K8 = K >> 3;
-    const long per = (long)K8 * N;
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= per) return;
-    const int oc = (int)(i / N), n = (int)(i - (long)oc * N);
-    float gm[8][3][3];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int k = oc * 8 + j;
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int q = 0; q < 3; ++q)
-                gm[j][r][q] = dgrad == 1 ? w[((long)((2 - r) * 3 + (2 - q)) * cin + n) * cout + k]
-                            : dgrad == 2 ? w[((long)(r * 3 + q) * cin + n) * cout + k] : w[((long)(r * 3 + q) * cin + k) * cout + n];
-    }
-    auto grow = [](const float g0, const float g1, const float g2, const int a) -> float {      // row a of G applied to (g0, g1, g2)
-        const float e = (g0 + g2) * (1.f / 6.f), f = g0 * (1.f / 24.f) + g2 * (1.f / 6.f);
-        switch (a) {
-        case 0: return 0.25f * g0;
-        case 1: return -e - g1 * (1.f / 6.f);
-        case 2: return -e + g1 * (1.f / 6.f);
-        case 3: return f + g1 * (1.f / 12.f);
-        case 4: return f - g1 * (1.f / 12.f);
-        default: return g2;
-        }
-    };
-#pragma unroll
-    for (int a = 0; a < 6; ++a) {
-        float u[6][8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float t0 = grow(gm[j][0][0], gm[j][1][0], gm[j][2][0], a), t1 = grow(gm[j][0][1], gm[j][1][1], gm[j][2][1], a),
-                        t2 = grow(gm[j][0][2], gm[j][1][2], gm[j][2][2], a);
-#pragma unroll
-            for (int b = 0; b < 6; ++b) u[b][j] = grow(t0, t1, t2, b);
-        }
-#pragma unroll
-        for (int b = 0; b < 6; ++b) {
-            w4_bf16x8 h, m, l;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float x = u[b][j];
-                const __bf16 hj = (__bf16)x;
-                const float r1 = x - (float)hj;
-                const __bf16 mj = (__bf16)r1;
-                h[j] = hj; m[j] = mj; l[j] = (__bf16)(r1 - (float)mj);
-            }
-            __bf16* d = Up + (long)(a * 6 + b) * 3 * per * 8 + i * 8;
-            *reinterpret_cast<w4_bf16x8*>(d) = h;
-            *reinterpret_cast<w4_bf16x8*>(d + per * 8) = m;
-            *reinterpret_cast<w4_bf16x8*>(d + 2 * per * 8) = l;
-        }
-    }
+    derive::wino4_weight_x3_body(w, Up, cin, cout, dgrad, blockIdx.x);
 }
 
 // dw[r][s][k][n] = (G^T (sum_splits dU[split][36][k][n]) G)[r][s]

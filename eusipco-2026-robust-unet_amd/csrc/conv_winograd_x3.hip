@@ -15,6 +15,7 @@
 //     (the f32 form: 16 MFMAs of 64 cycles).
 #include "x3_common.h"
 #include "../../include/runet_hip.h"
+#include "derive_weights.h"
 #include <stdlib.h>
 
 namespace {
@@ -296,57 +297,7 @@ __global__ __launch_bounds__(256, 2) void wino_conv_x3_kernel(WinoX3Args g) {
 
 // Up[xi][plane][K/8][N][8] = split(G g G^T);  forward: g[r][s] = w[r][s][k][n];  dgrad: g[r][s] = w[2-r][2-s][n][k].  thread = (k octet, n)
 __global__ __launch_bounds__(256) void wino_weight_x3_kernel(const float* __restrict__ w, __bf16* __restrict__ Up, int cin, int cout, int dgrad) {
-    const int K = dgrad ? cout : cin, N = dgrad ? cin : cout;
-    const int K8 = K >> 3;
-    const long per = (long)K8 * N;
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= per) return;
-    const int oc = (int)(i / N), n = (int)(i - (long)oc * N);
-    float gm[8][3][3];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int k = oc * 8 + j;
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int q = 0; q < 3; ++q)
-                gm[j][r][q] = dgrad ? w[((long)((2 - r) * 3 + (2 - q)) * cin + n) * cout + k] : w[((long)(r * 3 + q) * cin + k) * cout + n];
-    }
-    auto grow = [](const float g0, const float g1, const float g2, const int a) -> float {      // row a of G = [1,0,0; .5,.5,.5; .5,-.5,.5; 0,0,1]
-        switch (a) {
-        case 0: return g0;
-        case 1: return 0.5f * (g0 + g1 + g2);
-        case 2: return 0.5f * (g0 - g1 + g2);
-        default: return g2;
-        }
-    };
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        float u[4][8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float t0 = grow(gm[j][0][0], gm[j][1][0], gm[j][2][0], a), t1 = grow(gm[j][0][1], gm[j][1][1], gm[j][2][1], a),
-                        t2 = grow(gm[j][0][2], gm[j][1][2], gm[j][2][2], a);
-#pragma unroll
-            for (int b = 0; b < 4; ++b) u[b][j] = grow(t0, t1, t2, b);
-        }
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            bf16x8 h, m, l;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float x = u[b][j];
-                const __bf16 hj = (__bf16)x;
-                const float r1 = x - (float)hj;
-                const __bf16 mj = (__bf16)r1;
-                h[j] = hj; m[j] = mj; l[j] = (__bf16)(r1 - (float)mj);
-            }
-            __bf16* d = Up + (long)(a * 4 + b) * 3 * per * 8 + i * 8;
-            *reinterpret_cast<bf16x8*>(d) = h;
-            *reinterpret_cast<bf16x8*>(d + per * 8) = m;
-            *reinterpret_cast<bf16x8*>(d + 2 * per * 8) = l;
-        }
-    }
+    derive::wino_weight_x3_body(w, Up, cin, cout, dgrad, blockIdx.x);
 }
 
 }  // namespace

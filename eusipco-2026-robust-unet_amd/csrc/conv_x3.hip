@@ -16,6 +16,7 @@
 // share an A tile (all column tiles, and for the transposed forward all four taps) are adjacent in that order.
 #include "x3_common.h"
 #include "../../include/runet_hip.h"
+#include "derive_weights.h"
 #include <stdlib.h>
 
 namespace {
@@ -289,27 +290,7 @@ __global__ __launch_bounds__(256, 2) void conv_nn_x3_kernel(X3ConvArgs g) {
 // w (fp32) -> split planes dst[z][plane 3][k/8][n][8] bf16 with B_z[kk][col] = w[z * stride_z + kk * sk + col * sn]; thread = (z, octet, column)
 __global__ __launch_bounds__(256) void conv_x3_pack_kernel(const float* __restrict__ w, long stride_z, long sk, long sn, __bf16* __restrict__ dst, int batch,
                                                            int k, int n) {
-    const int K8 = k >> 3;
-    const long per = (long)K8 * n, total = per * batch;
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    const int z = (int)(i / per);
-    const long r = i - (long)z * per;
-    const int oc = (int)(r / n), col = (int)(r - (long)oc * n);
-    const float* s = w + (long)z * stride_z + (long)oc * 8 * sk + (long)col * sn;
-    bf16x8 h, m, l;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float x = s[(long)j * sk];
-        const __bf16 hj = (__bf16)x;
-        const float r1 = x - (float)hj;
-        const __bf16 mj = (__bf16)r1;
-        h[j] = hj; m[j] = mj; l[j] = (__bf16)(r1 - (float)mj);
-    }
-    __bf16* d = dst + (long)z * 3 * per * 8 + r * 8;
-    *reinterpret_cast<bf16x8*>(d) = h;
-    *reinterpret_cast<bf16x8*>(d + per * 8) = m;
-    *reinterpret_cast<bf16x8*>(d + 2 * per * 8) = l;
+    derive::pack_x3_body(w, stride_z, sk, sn, dst, batch, k, n, blockIdx.x);
 }
 
 bool mode_ok(int mode) { return mode == RUNET_CONV_FWD || mode == RUNET_CONV_DGRAD || mode == RUNET_CONVT_FWD || mode == RUNET_CONVT_DGRAD; }
@@ -340,12 +321,11 @@ extern "C" long runet_conv_x3_pack_elems(int cin, int cout, int mode) {
 extern "C" int runet_conv_x3_pack(const float* w, void* packed, int cin, int cout, int mode, void* stream) {
     RUNET_REQUIRE(w && packed && runet_conv_x3_supported(cin, cout, mode), "bad arguments (cin: multiple of 16, cout: multiple of 4)");
     RUNET_REQUIRE(((uintptr_t)packed % 16) == 0, "alignment");
-    const bool tr = mode == RUNET_CONV_DGRAD || mode == RUNET_CONVT_DGRAD;
-    const int taps = (mode == RUNET_CONVT_FWD || mode == RUNET_CONVT_DGRAD) ? 4 : 1;
+    int taps;
+    long stride_z, sk, sn;
+    derive::conv_x3_pack_strides(cin, cout, mode, taps, stride_z, sk, sn);
     const long total = (long)taps * (cin / 8) * cout;
-    // forward: B[k][n] = w[k][n] (row stride cout);  data gradient: B[k = Co][n = Ci] = w[n][k] (row stride = cin of this mode)
-    hipLaunchKernelGGL(conv_x3_pack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w, (long)cin * cout, tr ? 1L : (long)cout,
-                       tr ? (long)cin : 1L, (__bf16*)packed, taps, cin, cout);
+    hipLaunchKernelGGL(conv_x3_pack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w, stride_z, sk, sn, (__bf16*)packed, taps, cin, cout);
     RUNET_CHECK_LAUNCH();
 }
 

@@ -199,6 +199,8 @@ def dl_forward(net: DeepLabV3Plus, x, save=True):
     sm = B.Small(dev)
     n = x.shape[0]
     C = {}
+    if save:
+        ops.prefetch_derived(allow_side=False)      # the stale split-operand weights in one launch (DeepLabV3+ has no forward branches)
     x0 = B.to_nhwc_pad(x, 4)
     a1, C["conv1"] = _conv_bn_relu(x0, net.conv1[0], net.conv1[1], tr, sm, lambda t, w, b: ops.conv_general_fwd(t, w, b, 2, 3))
     _, h1, w1, c1 = a1.shape

@@ -6,6 +6,7 @@ channel slice of a wider concat buffer).  All launches go to torch's current HIP
 """
 from __future__ import annotations
 
+import ctypes
 import os
 import threading
 import weakref
@@ -93,9 +94,10 @@ def bump_weight_epoch():
         _derived.clear()
 
 
-def _cached(w, kind, make):
+def _cached(w, kind, make, desc=None):
     """make(out) -> the derived tensor (out = None: allocate; else refill that tensor in place).  make is kept in the cache entry (for
-    prefetch_derived) and must capture the weight's raw pointer, not the tensor: the entry holds the parameter by weak reference only."""
+    prefetch_derived) and must capture the weight's raw pointer, not the tensor: the entry holds the parameter by weak reference only.
+    desc = (RUNET_DERIVE_* kind, weight pointer, cin, cout, mode): the same refill as an entry of the multi-tensor launch (_derive_multi)."""
     base = w._base if w._base is not None else w
     key = (w.data_ptr(), kind)
     tag = (base._version, WEIGHT_EPOCH, tuple(w.shape))
@@ -110,21 +112,66 @@ def _cached(w, kind, make):
                 ev[1].add(sid)
         return hit[1]
     val = make(None)
-    _derived[key] = [tag, val, weakref.ref(base), make, None, base.data_ptr()]
+    _derived[key] = [tag, val, weakref.ref(base), make, None, base.data_ptr(), desc]
     return val
 
 
 PREFETCH_DERIVED = os.environ.get("RUNET_PREFETCH_DERIVED", "1") != "0"
+# All stale split-operand weights of a step in one launch (csrc/derive_multi.hip) instead of one launch per tensor (67 per Robust U-Net step).
+DERIVE_MULTI = os.environ.get("RUNET_NO_DERIVE_MULTI", "0") != "1"
+DERIVE_WINO4, DERIVE_WINO2, DERIVE_PACK = 0, 1, 2
+_derive_tables = {}
 
 
-def prefetch_derived():
-    """Called at the start of a training forward pass: refill, on the idle side stream, every derived weight (Winograd-domain filters,
-    packed bf16 / fp16 weights) that the optimizer step has made stale - in the order the previous step first used them, forward kinds
-    first.  The main stream waits for ONE event (recorded behind the forward kinds) the first time it touches a refilled entry, and for a
-    second one behind the data-gradient kinds; no per-entry events (those cost more than the launches they moved: an earlier version with
-    one event per entry was 0.7 % slower).  Refilled IN PLACE: every reader of the old values was enqueued before the optimizer launch,
-    which the side stream waits for.  -> number of entries refilled"""
-    if not (PREFETCH_DERIVED and FWD_BRANCHES and _branch_now and USE_WGRAD_STREAM and _derived) or torch.cuda.is_current_stream_capturing():
+def _derive_multi(entries):
+    """One launch on ops.stream() refilling, in place, every cache entry of `entries` (all with a descriptor).  The device table depends on
+    addresses only, so it is built and uploaded the first time a set of entries is seen - never during a stream capture (-> False then)."""
+    key = tuple((ent[6], ent[1].data_ptr()) for ent in entries)
+    tab = _derive_tables.get(key)
+    if tab is None:
+        if torch.cuda.is_current_stream_capturing():
+            return False
+        nb = lib.runet_derive_desc_bytes()
+        host = ctypes.create_string_buffer(nb * len(entries))
+        first = 0
+        for i, ent in enumerate(entries):
+            kind, wp, cin, cout, mode = ent[6]
+            blocks = lib.runet_derive_desc(ctypes.addressof(host), i, kind, wp, ent[1].data_ptr(), cin, cout, mode, first)
+            if blocks <= 0:
+                raise RuntimeError(f"runet_derive_desc refused entry {ent[6]}")
+            first += blocks
+        table = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(entries[0][1].device)
+        if len(_derive_tables) >= 64:
+            if PIN_SCRATCH:                      # a captured step may hold the address of a table
+                _retired.extend(t[0] for t in _derive_tables.values())
+            _derive_tables.clear()
+        tab = _derive_tables[key] = (table, len(entries), first)
+    check(lib.runet_derive_multi(tab[0].data_ptr(), tab[1], tab[2], stream()))
+    return True
+
+
+def _refill(group):
+    """group: [(entry, base)] stale entries -> refilled in place on ops.stream(): those with a descriptor in one launch, the rest one by one."""
+    multi = [e for e, _ in group if e[6] is not None] if DERIVE_MULTI else []
+    done = len(multi) >= 2 and _derive_multi(multi)
+    for ent, base in group:
+        if not (done and ent[6] is not None):
+            ent[3](ent[1])
+        ent[0] = (base._version, WEIGHT_EPOCH, ent[0][2])
+
+
+def prefetch_derived(allow_side=True):
+    """Called at the start of a training forward pass: refill every derived weight (Winograd-domain filters, packed split-operand / bf16 /
+    fp16 weights) that the optimizer step has made stale.  GPU-bound step sizes: on the idle side stream, in the order the previous step
+    first used them, forward kinds first.  The main stream waits for ONE event (recorded behind the forward kinds) the first time it touches
+    a refilled entry, and for a second one behind the data-gradient kinds; no per-entry events (those cost more than the launches they moved:
+    an earlier version with one event per entry was 0.7 % slower).  Otherwise (small steps, no side stream, a hipGraph capture): the entries
+    of the multi-tensor launch on the current stream, the rest lazily at their first use as before.  Refilled IN PLACE: every reader of the
+    old values was enqueued before the optimizer launch, which the stream used here is ordered behind.  -> number of entries refilled"""
+    if not (PREFETCH_DERIVED and _derived):
+        return 0
+    on_side = allow_side and FWD_BRANCHES and _branch_now and USE_WGRAD_STREAM and not torch.cuda.is_current_stream_capturing()
+    if not on_side and (not DERIVE_MULTI or _side.get("active") is not None):
         return 0
     todo = []
     for key, ent in list(_derived.items()):
@@ -137,6 +184,14 @@ def prefetch_derived():
             todo.append((key[1].endswith("d") or key[1].endswith("t") or key[1] == "T", ent, base))
     if not todo:
         return 0
+    if not on_side:
+        group = [(e, b) for _, e, b in todo if e[6] is not None]
+        if len(group) < 2 or not _derive_multi([e for e, _ in group]):
+            return 0
+        for ent, base in group:
+            ent[0] = (base._version, WEIGHT_EPOCH, ent[0][2])
+            ent[4] = None
+        return len(group)
     br = side_branch()
     if br.s is None:
         return 0
@@ -146,9 +201,7 @@ def prefetch_derived():
             group = [(e, b) for is_bwd, e, b in todo if is_bwd == want_bwd]
             if not group:
                 continue
-            for ent, base in group:
-                ent[3](ent[1])
-                ent[0] = (base._version, WEIGHT_EPOCH, ent[0][2])
+            _refill(group)
             ev = [torch.cuda.Event(), {side_id}]
             ev[0].record(br.s)
             for ent, _ in group:
@@ -385,7 +438,7 @@ def conv_x3_weights(w_hwio, mode):
         buf = out if out is not None else torch.empty(lib.runet_conv_x3_pack_elems(k, n, mode), device=dev, dtype=torch.bfloat16)
         check(lib.runet_conv_x3_pack(wp, buf.data_ptr(), k, n, mode, stream()))
         return buf
-    return _cached(w_hwio, _X3_KIND[mode], make)
+    return _cached(w_hwio, _X3_KIND[mode], make, desc=(DERIVE_PACK, wp, k, n, mode))
 
 
 # BatchNorm statistics taken in the producing convolution's epilogue (runet_conv_x3_stats / runet_wino_conv_x3_stats) instead of by a pass of
@@ -459,7 +512,7 @@ def wino_weights(w_hwio, dgrad=False):
             check(lib.runet_wino_weights_x3(wp, Up.data_ptr(), cin, cout, int(dgrad), stream()))
             Up.kn = (k, n)
             return Up
-        return _cached(w_hwio, "wino2xd" if dgrad else "wino2x", make_x3)
+        return _cached(w_hwio, "wino2xd" if dgrad else "wino2x", make_x3, desc=(DERIVE_WINO2, wp, cin, cout, int(dgrad)))
 
     def make(out):
         U = out if out is not None else torch.empty((16, k, n), device=dev, dtype=torch.float32)
@@ -974,7 +1027,8 @@ def wino4_weights(w_hwio, dgrad=False, adjoint=False):
             check(lib.runet_wino4_weights_x3(wp, Up.data_ptr(), cin, cout, 2 if adjoint else int(dgrad), stream()))      # transform + split in one pass
             Up.kn = (k, n)
             return Up
-        return _cached(w_hwio, "wino4xad" if adjoint else ("wino4xd" if dgrad else "wino4x"), make_x3)
+        return _cached(w_hwio, "wino4xad" if adjoint else ("wino4xd" if dgrad else "wino4x"), make_x3,
+                       desc=(DERIVE_WINO4, wp, cin, cout, 2 if adjoint else int(dgrad)))
     assert not adjoint, "the adjoint data gradient exists for the split-operand path only"
 
     def make(out):

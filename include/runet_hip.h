@@ -278,6 +278,16 @@ int runet_conv_x3_pack(const float* w, void* packed, int cin, int cout, int mode
 int runet_conv_x3(const float* x, int ldx, const void* wpacked, const float* bias, float* y, int ldy, int n_img, int h, int w, int cin, int cout,
                   int mode, int accumulate, void* stream);
 const char* runet_conv_x3_kernel_name(int n_img, int h, int w, int cout, int mode);
+
+/* ---- every derived weight of a step in one launch (csrc/derive_multi.hip).  The split-operand kernels read their weights as bf16 planes made
+ * by runet_wino4_weights_x3 / runet_wino_weights_x3 / runet_conv_x3_pack once per optimizer step (the reference has no such step: its weights
+ * are read as they are, Main_Final.py:123-134, 261-270); these three calls batch them: fill a host table with runet_derive_desc (same arguments as
+ * the per-tensor call of that kind; returns the entry's block count, < 0 on bad arguments), copy it to the device, launch runet_derive_multi.
+ * Results are bit-identical to the per-tensor calls. */
+enum { RUNET_DERIVE_WINO4 = 0, RUNET_DERIVE_WINO2 = 1, RUNET_DERIVE_PACK = 2 };
+int runet_derive_desc_bytes(void);
+int runet_derive_desc(void* host_table, int index, int kind, const float* w, void* dst, int cin, int cout, int mode, int first_block);
+int runet_derive_multi(const void* table, int n_desc, int total_blocks, void* stream);
 /* the 1x1 modes with the BatchNorm statistics of the output taken in the epilogue: stats [runet_conv_x3_stats_parts(n_img, h, w)][cout][3] */
 int runet_conv_x3_stats_parts(int n_img, int h, int w);
 int runet_conv_x3_stats(const float* x, int ldx, const void* wpacked, const float* bias, float* y, int ldy, int n_img, int h, int w, int cin, int cout,

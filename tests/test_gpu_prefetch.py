@@ -10,11 +10,17 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def _run(pkg, oracle, flags, precision, steps=5):
+def _run(pkg, oracle, flags, precision, steps=5, multi=True, calls=None):
     ops = importlib.import_module("eusipco-2026-robust-unet_amd.ops")
     trainer = importlib.import_module("eusipco-2026-robust-unet_amd.trainer")
-    old = ops.PREFETCH_DERIVED, ops.FWD_BRANCHES, ops.BRANCH_MIN_PIXELS
+    old = ops.PREFETCH_DERIVED, ops.FWD_BRANCHES, ops.BRANCH_MIN_PIXELS, ops.DERIVE_MULTI, ops._derive_multi
     ops.PREFETCH_DERIVED, ops.FWD_BRANCHES = flags
+    ops.DERIVE_MULTI = multi
+    if calls is not None:
+        def counted(entries, real=ops._derive_multi):
+            calls.append(len(entries))
+            return real(entries)
+        ops._derive_multi = counted
     ops.BRANCH_MIN_PIXELS = 0                         # the models switch branching off for small (host-bound) steps: force it for 2 x 64^2
     ops._derived.clear()
     try:
@@ -31,7 +37,7 @@ def _run(pkg, oracle, flags, precision, steps=5):
         torch.cuda.synchronize()
         return m, losses, refilled
     finally:
-        ops.PREFETCH_DERIVED, ops.FWD_BRANCHES, ops.BRANCH_MIN_PIXELS = old
+        ops.PREFETCH_DERIVED, ops.FWD_BRANCHES, ops.BRANCH_MIN_PIXELS, ops.DERIVE_MULTI, ops._derive_multi = old
 
 
 @pytest.mark.parametrize("precision", ["f32", "bf16", "fp16"])
@@ -46,6 +52,66 @@ def test_prefetch_and_branches_change_nothing(pkg, oracle, precision):
         assert torch.equal(pa, pb), k
     for (k, ba), (_, bb) in zip(ma.named_buffers(), mb.named_buffers()):
         assert torch.equal(ba, bb), k
+
+
+@pytest.mark.parametrize("branches", [True, False])
+def test_multi_tensor_refill_changes_nothing(pkg, oracle, branches):
+    """the stale split-operand weights of a step in ONE launch (csrc/derive_multi.hip) - on the side stream with forward branches, on the
+    current stream without - against one launch per tensor: same losses, parameters and buffers, bit for bit"""
+    calls = []
+    ma, la, _ = _run(pkg, oracle, (True, branches), "f32", calls=calls)
+    mb, lb, _ = _run(pkg, oracle, (True, branches), "f32", multi=False)
+    assert calls and max(calls) >= 20, f"the multi-tensor launch did not carry the step's derived weights: {calls}"
+    for i, (a, b) in enumerate(zip(la, lb)):
+        assert torch.equal(a, b), (i, float(a), float(b))
+    for (k, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+        assert torch.equal(pa, pb), k
+    for (k, ba), (_, bb) in zip(ma.named_buffers(), mb.named_buffers()):
+        assert torch.equal(ba, bb), k
+
+
+def test_multi_tensor_refill_matches_the_per_tensor_entry_points():
+    """runet_derive_multi over a table of all three kinds and every mode == runet_wino4_weights_x3 / runet_wino_weights_x3 / runet_conv_x3_pack"""
+    import ctypes
+    L = importlib.import_module("eusipco-2026-robust-unet_amd._lib")
+    lib, check = L.lib, L.check
+    g = torch.Generator().manual_seed(11)
+    st = torch.cuda.current_stream().cuda_stream
+    cases = []
+    for cin, cout in ((128, 256), (256, 128), (64, 64)):
+        w = torch.randn((3, 3, cin, cout), generator=g).to(DEV)
+        for mode in (0, 1, 2):
+            k, n = (cout, cin) if mode else (cin, cout)
+            cases.append((0, w, cin, cout, mode, lib.runet_gemm_x3_pack_elems(36, k, n)))
+        for mode in (0, 1):
+            k, n = (cout, cin) if mode else (cin, cout)
+            cases.append((1, w, cin, cout, mode, lib.runet_wino_x3_pack_elems(k, n)))
+    for cin, cout, mode in ((128, 64, 0), (64, 128, 1), (256, 128, 2), (128, 256, 3)):        # cin: channels READ in that mode
+        ci_w, co_w = (cout, cin) if mode in (1, 3) else (cin, cout)
+        w = torch.randn((2 if mode >= 2 else 1, 2 if mode >= 2 else 1, ci_w, co_w), generator=g).to(DEV)
+        cases.append((2, w, cin, cout, mode, lib.runet_conv_x3_pack_elems(cin, cout, mode)))
+    one, many = [], []
+    nb = lib.runet_derive_desc_bytes()
+    host = ctypes.create_string_buffer(nb * len(cases))
+    first = 0
+    for i, (kind, w, cin, cout, mode, elems) in enumerate(cases):
+        a = torch.zeros(elems, device=DEV, dtype=torch.bfloat16)
+        b = torch.zeros(elems, device=DEV, dtype=torch.bfloat16)
+        fn = (lib.runet_wino4_weights_x3, lib.runet_wino_weights_x3, lib.runet_conv_x3_pack)[kind]
+        check(fn(w.data_ptr(), a.data_ptr(), cin, cout, mode, st))
+        blocks = lib.runet_derive_desc(ctypes.addressof(host), i, kind, w.data_ptr(), b.data_ptr(), cin, cout, mode, first)
+        assert blocks > 0, (kind, cin, cout, mode)
+        first += blocks
+        one.append(a)
+        many.append(b)
+    table = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(DEV)
+    check(lib.runet_derive_multi(table.data_ptr(), len(cases), first, st))
+    torch.cuda.synchronize()
+    for (kind, w, cin, cout, mode, _), a, b in zip(cases, one, many):
+        assert bool(a.float().abs().sum() > 0)
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16)), (kind, cin, cout, mode)
+    assert lib.runet_derive_desc(ctypes.addressof(host), 0, 7, w.data_ptr(), b.data_ptr(), 64, 64, 0, 0) < 0
+    assert lib.runet_derive_desc(ctypes.addressof(host), 0, 0, w.data_ptr(), b.data_ptr(), 60, 64, 0, 0) < 0
 
 
 def test_torch_side_weight_write_is_seen(pkg, oracle):
