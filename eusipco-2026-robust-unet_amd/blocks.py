@@ -295,10 +295,16 @@ def rb_forward(x, p: RBParams, training, mask=None, save=True, stats_hook=None):
     else:
         s1, h1, mean1, invstd1, _ = bn_coeff(t1, p.bn1, training, sm, stats_hook=stats_hook, fused=f1)
     use_mask = mask if training else None
-    a1 = bn_apply(t1, s1, h1, use_mask, relu=True)
+    if ops.fuses_act_input(t1, p.w2):
+        # conv2 on the F(4x4) path: BatchNorm + ReLU + Dropout2d ride in its input transform's loads, a1 is never written (rb_a1 recomputes it
+        # for whoever wants to look at it); the backward pass needs t1 and the kept V only
+        a1 = None
+        t2 = ops.conv_fwd(t1, p.w2, keep_v=kv2, pre=(s1, h1, use_mask))
+    else:
+        a1 = bn_apply(t1, s1, h1, use_mask, relu=True)
+        t2 = ops.conv_fwd(a1, p.w2, keep_v=kv2)
     if not save:
         del t1
-    t2 = ops.conv_fwd(a1, p.w2, keep_v=kv2)
     s2, h2, mean2, invstd2, nc = bn_coeff(t2, p.bn2, training, sm, want_minmax=True, stats_hook=stats_hook)
     mean_nc, _, max_nc, min_nc, imax, imin = nc
     A, B, ca, avg, mx, tval = (sm.f(n * c) for _ in range(6))
@@ -323,6 +329,14 @@ def rb_forward(x, p: RBParams, training, mask=None, save=True, stats_hook=None):
                mean2=mean2, invstd2=invstd2, ss=ss, mean_s=mean_s, invstd_s=invstd_s, A=A, B=B, ca=ca, avg=avg, mx=mx, idx=idx,
                tval=tval, mean_nc=mean_nc, smap=smap, amax=amax, sa=sa, v1=kv1.get("V"), v2=kv2.get("V"))
     return out, ctx
+
+
+def rb_a1(ctx):
+    """The activation between conv1 and conv2, relu(bn1(conv1 x)) * dropout mask: saved, or - where conv2's input transform produced it on the
+    fly (rb_forward) - evaluated by the same expression (bn_apply_kernel and the fused transform share bn_pre: identical bits)."""
+    if ctx["a1"] is not None:
+        return ctx["a1"]
+    return bn_apply(ctx["t1"], ctx["s1"], ctx["h1"], ctx["mask"], relu=True)
 
 
 def rb_backward(ctx, dout, sink, pre="", need_dx=True):
@@ -385,16 +399,35 @@ def rb_backward(ctx, dout, sink, pre="", need_dx=True):
     # the data gradient first: on the adjoint F(4x4) path it leaves Z = A dy A^T behind, which the weight gradient (side stream) reuses
     kz = {}
     da1 = ops.conv_dgrad(dt2, p.w2, keep_z=kz)
+    if a1 is None:
+        assert ctx.get("v2") is not None, "conv2 took its activation on the fly: its weight gradient needs the kept V"
+        a1 = t1                                        # shape only: the weight gradient reads V
     ops.conv_wgrad(a1, dt2, 3, 3, out=sink.buf(pre, [("conv2.weight", (3, 3, c, c))]), v=ctx.get("v2"), z=kz.get("Z"))
     ctx["v2"] = None
     del dt2, kz
     sums1 = sink.buf(pre, [("bn1.weight", (c,)), ("bn1.bias", (c,))])
-    dt1 = bn_backward(da1, t1, ctx["mean1"], ctx["invstd1"], ctx["s1"], sums1, mask=ctx["mask"], out=da1, sync=sync, relu_shift=ctx["h1"], training=tr)
-    # the first block of the network (need_dx False) ends the backward chain: nothing is left on the main stream to overlap with, so its
-    # last weight gradient runs there, next to the conv2 weight gradient still on the side stream
     kz1, dx1 = {}, None
-    if need_dx and p.ws is not None:
-        dx1 = ops.conv_dgrad(dt1, p.w1, keep_z=kz1)
+    fused_dt1 = need_dx and p.cin_w == x.shape[3] and ops.fuses_bn_bwd_input(da1, p.w1)
+    if fused_dt1:
+        # conv1 on the adjoint F(4x4) path: the BatchNorm-backward dx rides in the loads of Z = A dt1 A^T, which both of conv1's gradients read
+        # - dt1 itself is never written (two passes over the tensor and one launch less)
+        bn_bwd_reduce(da1, t1, ctx["mean1"], ctx["invstd1"], ctx["s1"], sums1, None, ctx["mask"], ctx["h1"])
+        if not tr:
+            use1, m1 = zeros(2 * c, dev), 0
+        else:
+            use1, m1 = (sums1, 0) if sync is None else sync.reduce_sums(sums1, P)
+        bn1 = dict(x=t1, mean=ctx["mean1"], invstd=ctx["invstd1"], scale=ctx["s1"], shift=ctx["h1"], sums=use1, m_total=m1, mask=ctx["mask"])
+        if p.ws is not None:
+            dx1 = ops.conv_dgrad(da1, p.w1, keep_z=kz1, bn=bn1)
+        else:
+            dx1 = ops.conv_dgrad(da1, p.w1, out=dv, accumulate=True, keep_z=kz1, bn=bn1)
+        dt1 = da1                                      # shape only: the weight gradient reads Z
+    else:
+        dt1 = bn_backward(da1, t1, ctx["mean1"], ctx["invstd1"], ctx["s1"], sums1, mask=ctx["mask"], out=da1, sync=sync, relu_shift=ctx["h1"], training=tr)
+        # the first block of the network (need_dx False) ends the backward chain: nothing is left on the main stream to overlap with, so its
+        # last weight gradient runs there, next to the conv2 weight gradient still on the side stream
+        if need_dx and p.ws is not None:
+            dx1 = ops.conv_dgrad(dt1, p.w1, keep_z=kz1)
     ops.conv_wgrad(x, dt1, 3, 3, cin_w=p.cin_w, out=sink.buf(pre, [("conv1.weight", (3, 3, p.cin_w, c))]), v=ctx.get("v1"), on_side=need_dx,
                    z=kz1.get("Z"))
     ctx["v1"] = None
@@ -413,7 +446,8 @@ def rb_backward(ctx, dout, sink, pre="", need_dx=True):
             ops.conv_dgrad(dr, p.ws, out=dx, accumulate=True)
     elif need_dx:
         dx = dv
-        ops.conv_dgrad(dt1, p.w1, out=dx, accumulate=True)
+        if not fused_dt1:
+            ops.conv_dgrad(dt1, p.w1, out=dx, accumulate=True)
     return dx
 
 

@@ -47,9 +47,20 @@ __device__ __forceinline__ long pix(const W4Geom& g, int n, int ih, int iw) {   
     return (long)nf * g.img_px + (long)(ih * g.D + oy) * g.WF + (iw * g.D + ox);
 }
 
+// The elementwise producer of a transform's input, folded into its loads (ACT) so that the tensor between the two is never written:
+//   MODE 0: src = the convolution output t in front of BatchNorm + ReLU (+ Dropout2d): the patch is max(t * scale + shift, 0) * factor[n][c],
+//           i.e. bn_apply_kernel(relu) on the fly (same bn_pre -> bit-identical), zero outside the image;
+//   MODE 1: src = dy of that activation, x = t: the tile is the BatchNorm-backward dx of bn_bwd_apply_kernel(relu_shift) on the fly.
+struct W4Pre {
+    const float *scale, *shift, *factor;
+    const float *x, *mean, *invstd, *sums;
+    int ldx;
+    float inv_m;
+};
+
 // MODE 0: src = conv input (or dy for the data gradient), 6x6 patch at (4ty-1, 4tx-1);  MODE 1: src = dy, 4x4 tile at (4ty, 4tx)
-template <int MODE>
-__global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restrict__ src, int ld, int C, W4Geom g, float* __restrict__ V) {
+template <int MODE, bool ACT = false>
+__global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restrict__ src, int ld, int C, W4Geom g, float* __restrict__ V, W4Pre pre = W4Pre{}) {
     const int C2 = C >> 1;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= g.T * C2) return;
@@ -60,6 +71,20 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restric
     const int rem = (int)(tile - (long)n * per);
     const int ty = rem / g.TX, tx = rem - ty * g.TX;
     f32x2 d[6][6];
+    f32x2 psc = {1.f, 1.f}, psh = {0.f, 0.f}, pfa = {1.f, 1.f}, pca = {0.f, 0.f}, pcb = {0.f, 0.f};
+    if constexpr (ACT) {
+        const int nf = n / (g.D * g.D);                    // image of the full tensor (factor is per image and channel)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            psc[q] = pre.scale[c + q]; psh[q] = pre.shift[c + q];
+            pfa[q] = pre.factor ? pre.factor[(long)nf * C + c + q] : 1.f;
+            if constexpr (MODE == 1) {
+                float a, b;
+                bn_bwd_coef(psc[q], pre.mean[c + q], pre.invstd[c + q], pre.sums[c + q], pre.sums[C + c + q], pre.inv_m, a, b);
+                pca[q] = a; pcb[q] = b;
+            }
+        }
+    }
     if constexpr (MODE == 0) {
         const int h0 = 4 * ty - 1, w0 = 4 * tx - 1;
 #pragma unroll
@@ -69,7 +94,11 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restric
                 const int ih = h0 + i, iw = w0 + j;
                 const bool ok = (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
                 const long off = ok ? pix(g, n, ih, iw) * ld + c : 0;
-                const f32x2 v = *reinterpret_cast<const f32x2*>(src + off);
+                f32x2 v = *reinterpret_cast<const f32x2*>(src + off);
+                if constexpr (ACT) {
+                    v[0] = fmaxf(bn_pre(v[0], psc[0], psh[0]), 0.f) * pfa[0];
+                    v[1] = fmaxf(bn_pre(v[1], psc[1], psh[1]), 0.f) * pfa[1];
+                }
                 d[i][j] = ok ? v : f32x2{0.f, 0.f};
             }
 #pragma unroll
@@ -80,10 +109,23 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restric
         f32x2 y[4][4], t[6][4];
         const float* base = src + pix(g, n, 4 * ty, 4 * tx) * ld + c;
         const long rs = (long)g.D * g.WF * ld, ps = (long)g.D * ld;          // row / pixel stride inside the sub-image
+        const float* xbase = ACT ? pre.x + pix(g, n, 4 * ty, 4 * tx) * pre.ldx + c : nullptr;
+        const long xrs = (long)g.D * g.WF * pre.ldx, xps = (long)g.D * pre.ldx;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) y[i][j] = *reinterpret_cast<const f32x2*>(base + i * rs + j * ps);
+            for (int j = 0; j < 4; ++j) {
+                f32x2 v = *reinterpret_cast<const f32x2*>(base + i * rs + j * ps);
+                if constexpr (ACT) {
+                    const f32x2 xv = *reinterpret_cast<const f32x2*>(xbase + i * xrs + j * xps);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const float gg = (bn_pre(xv[q], psc[q], psh[q]) > 0.f) ? v[q] * pfa[q] : 0.f;
+                        v[q] = bn_bwd_dx(gg, psc[q], xv[q], pca[q], pcb[q]);
+                    }
+                }
+                y[i][j] = v;
+            }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             f32x2 z[6];
@@ -362,8 +404,40 @@ extern "C" int runet_wino4_input(const float* src, int ld, int c, int n_img, int
     RUNET_REQUIRE(src && V && dil_ok(h, w, dil) && runet_wino4_supported(h / dil, w / dil, 16, 4) && c > 0 && c % 2 == 0 && ld >= c && ld % 2 == 0, "bad arguments");
     RUNET_REQUIRE(((uintptr_t)src % 8) == 0 && ((uintptr_t)V % 8) == 0 && (mode == 0 || mode == 1), "alignment / mode");
     const W4Geom g = geom(n_img, h, w, dil);
-    if (mode == 0) hipLaunchKernelGGL(wino4_input_kernel<0>, dim3(cdiv(g.T * (c / 2), 256)), dim3(256), 0, (hipStream_t)stream, src, ld, c, g, V);
-    else hipLaunchKernelGGL(wino4_input_kernel<1>, dim3(cdiv(g.T * (c / 2), 256)), dim3(256), 0, (hipStream_t)stream, src, ld, c, g, V);
+    if (mode == 0) hipLaunchKernelGGL(wino4_input_kernel<0>, dim3(cdiv(g.T * (c / 2), 256)), dim3(256), 0, (hipStream_t)stream, src, ld, c, g, V, W4Pre{});
+    else hipLaunchKernelGGL(wino4_input_kernel<1>, dim3(cdiv(g.T * (c / 2), 256)), dim3(256), 0, (hipStream_t)stream, src, ld, c, g, V, W4Pre{});
+    RUNET_CHECK_LAUNCH();
+}
+
+// runet_wino4_input(mode 0) of a1 = max(t * scale + shift, 0) * factor_nc[n][c] (runet_bn_apply with relu = 1) without a1 ever being written:
+// V is bit-identical to the two-step form.  factor_nc may be NULL.
+extern "C" int runet_wino4_input_act(const float* t, int ld, int c, int n_img, int h, int w, int dil, const float* scale, const float* shift,
+                                     const float* factor_nc, float* V, void* stream) {
+    RUNET_REQUIRE(t && V && scale && shift && dil_ok(h, w, dil) && runet_wino4_supported(h / dil, w / dil, 16, 4) && c > 0 && c % 2 == 0 && ld >= c && ld % 2 == 0,
+                  "bad arguments");
+    RUNET_REQUIRE(((uintptr_t)t % 8) == 0 && ((uintptr_t)V % 8) == 0, "alignment");
+    const W4Geom g = geom(n_img, h, w, dil);
+    W4Pre pre{};
+    pre.scale = scale; pre.shift = shift; pre.factor = factor_nc;
+    hipLaunchKernelGGL((wino4_input_kernel<0, true>), dim3(cdiv(g.T * (c / 2), 256)), dim3(256), 0, (hipStream_t)stream, t, ld, c, g, V, pre);
+    RUNET_CHECK_LAUNCH();
+}
+
+// runet_wino4_input(mode 1) of dx = runet_bn_bwd_apply(dy, x, ..., relu_shift = shift) without dx ever being written: Z = A dx A^T, bit-identical
+// to the two-step form.  sums [2c] = (sum g * xhat | sum g) as runet_bn_bwd_reduce leaves them (zeros in eval mode), m_total as there (0: the
+// tensor's own pixel count).
+extern "C" int runet_wino4_input_bn_bwd(const float* dy, int lddy, const float* x, int ldx, int c, int n_img, int h, int w, int dil, const float* mean,
+                                        const float* invstd, const float* scale, const float* shift, const float* sums, const float* factor_nc,
+                                        long m_total, float* Z, void* stream) {
+    RUNET_REQUIRE(dy && x && Z && mean && invstd && scale && shift && sums, "null pointer");
+    RUNET_REQUIRE(dil_ok(h, w, dil) && runet_wino4_supported(h / dil, w / dil, 16, 4) && c > 0 && c % 2 == 0 && lddy >= c && lddy % 2 == 0 && ldx >= c &&
+                  ldx % 2 == 0, "bad arguments");
+    RUNET_REQUIRE(((uintptr_t)dy % 8) == 0 && ((uintptr_t)x % 8) == 0 && ((uintptr_t)Z % 8) == 0, "alignment");
+    const W4Geom g = geom(n_img, h, w, dil);
+    W4Pre pre{};
+    pre.scale = scale; pre.shift = shift; pre.factor = factor_nc; pre.x = x; pre.ldx = ldx; pre.mean = mean; pre.invstd = invstd; pre.sums = sums;
+    pre.inv_m = 1.0f / (float)(m_total > 0 ? m_total : (long)n_img * h * w);
+    hipLaunchKernelGGL((wino4_input_kernel<1, true>), dim3(cdiv(g.T * (c / 2), 256)), dim3(256), 0, (hipStream_t)stream, dy, lddy, c, g, Z, pre);
     RUNET_CHECK_LAUNCH();
 }
 
@@ -409,7 +483,7 @@ extern "C" int runet_wino4_conv(const float* x, int ldx, const float* U, const f
     hipStream_t st = (hipStream_t)stream;
     float* V = workspace;
     float* M = workspace + 36L * g.T * k;
-    hipLaunchKernelGGL(wino4_input_kernel<0>, dim3(cdiv(g.T * (k / 2), 256)), dim3(256), 0, st, x, ldx, k, g, V);
+    hipLaunchKernelGGL(wino4_input_kernel<0>, dim3(cdiv(g.T * (k / 2), 256)), dim3(256), 0, st, x, ldx, k, g, V, W4Pre{});
     const int rc = runet_gemm_batched(V, k, g.T * k, U, (long)k * n, M, n, g.T * n, 36, (int)g.T, k, n, stream);
     if (rc) return rc;
     hipLaunchKernelGGL(wino4_output_kernel, dim3(cdiv(g.T * (n / 2), 256)), dim3(256), 0, st, M, n, g, bias, y, ldy, accumulate);
@@ -431,7 +505,7 @@ extern "C" int runet_wino4_conv_x3(const float* x, int ldx, const void* Upacked,
     hipStream_t st = (hipStream_t)stream;
     float* V = workspace;
     float* M = workspace + 36L * g.T * k;
-    hipLaunchKernelGGL(wino4_input_kernel<0>, dim3(cdiv(g.T * (k / 2), 256)), dim3(256), 0, st, x, ldx, k, g, V);
+    hipLaunchKernelGGL(wino4_input_kernel<0>, dim3(cdiv(g.T * (k / 2), 256)), dim3(256), 0, st, x, ldx, k, g, V, W4Pre{});
     const int rc = runet_gemm_x3_batched(V, k, g.T * k, Upacked, M, n, g.T * n, 36, (int)g.T, k, n, stream);
     if (rc) return rc;
     hipLaunchKernelGGL(wino4_output_kernel, dim3(cdiv(g.T * (n / 2), 256)), dim3(256), 0, st, M, n, g, bias, y, ldy, accumulate);
@@ -457,8 +531,8 @@ extern "C" int runet_wino4_wgrad(const float* x, int ldx, const float* dy, int l
     float* dU = Z + 36L * g.T * cout;
     const int rps = wgrad_rows_per_split(g.T, cin, cout);
     const int splits = cdiv(g.T, rps);
-    hipLaunchKernelGGL(wino4_input_kernel<0>, dim3(cdiv(g.T * (cin / 2), 256)), dim3(256), 0, st, x, ldx, cin, g, V);
-    hipLaunchKernelGGL(wino4_input_kernel<1>, dim3(cdiv(g.T * (cout / 2), 256)), dim3(256), 0, st, dy, ldy, cout, g, Z);
+    hipLaunchKernelGGL(wino4_input_kernel<0>, dim3(cdiv(g.T * (cin / 2), 256)), dim3(256), 0, st, x, ldx, cin, g, V, W4Pre{});
+    hipLaunchKernelGGL(wino4_input_kernel<1>, dim3(cdiv(g.T * (cout / 2), 256)), dim3(256), 0, st, dy, ldy, cout, g, Z, W4Pre{});
     const int rc = runet_gemm_tn_batched(V, cin, g.T * cin, Z, cout, g.T * cout, dU, 36, (int)g.T, cin, cout, rps, stream);
     if (rc) return rc;
     const long kn = (long)cin * cout;

@@ -323,7 +323,7 @@ __global__ __launch_bounds__(TPB) void bn_apply_kernel(const float* __restrict__
         } else v[0] = x[(ib + p) * ldx + col];
 #pragma unroll
         for (int q = 0; q < VEC; ++q) {
-            float r = v[q] * sc[q] + sh[q];
+            float r = bn_pre(v[q], sc[q], sh[q]);
             if (relu) r = fmaxf(r, 0.f);
             v[q] = r * mk[q];
         }
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_partial(const float* __rest
             for (int q = 0; q < VEC; ++q) {
                 float gg = g[q];
                 if (act) gg = (av[q] > 0.f) ? gg * mk[q] : 0.f;
-                else if (recompute) gg = (xv[q] * fs[q] + fh[q] > 0.f) ? gg * mk[q] : 0.f;
+                else if (recompute) gg = (bn_pre(xv[q], fs[q], fh[q]) > 0.f) ? gg * mk[q] : 0.f;
                 sg[q] += gg;
                 sgx[q] += gg * (xv[q] - mu[q]) * is[q];
             }
@@ -449,8 +449,8 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const float* __restri
 #pragma unroll
     for (int q = 0; q < VEC; ++q) {
         const int c = col * VEC + q;
-        const float s = scale[c], k1 = sums[C + c] * inv_m, k2 = sums[c] * inv_m, is = invstd[c];
-        sc[q] = s; ca[q] = -s * k2 * is; cb[q] = s * (mean[c] * is * k2 - k1);
+        sc[q] = scale[c];
+        bn_bwd_coef(sc[q], mean[c], invstd[c], sums[c], sums[C + c], inv_m, ca[q], cb[q]);
         mk[q] = mask ? mask[(long)n * C + c] : 1.f;
         fh[q] = recompute ? rshift[c] : 0.f;
     }
@@ -475,8 +475,8 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const float* __restri
         for (int q = 0; q < VEC; ++q) {
             float gg = g[q];
             if (act) gg = (av[q] > 0.f) ? gg * mk[q] : 0.f;
-            else if (recompute) gg = (xv[q] * sc[q] + fh[q] > 0.f) ? gg * mk[q] : 0.f;
-            r[q] = gg * sc[q] + xv[q] * ca[q] + cb[q];
+            else if (recompute) gg = (bn_pre(xv[q], sc[q], fh[q]) > 0.f) ? gg * mk[q] : 0.f;
+            r[q] = bn_bwd_dx(gg, sc[q], xv[q], ca[q], cb[q]);
         }
         if constexpr (VEC == 4) {
             f32x4 t = {r[0], r[1], r[2], r[3]};

@@ -63,3 +63,20 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// BatchNorm pieces that several kernels must evaluate BIT-IDENTICALLY (bn_apply_kernel, the backward kernels that recompute the ReLU mask from
+// x, the F(4x4) input transforms that take the BatchNorm in their loads): explicit FMAs, so the roundings do not depend on what the compiler
+// contracts in each kernel.
+__device__ __forceinline__ float bn_pre(const float x, const float scale, const float shift) { return __builtin_fmaf(x, scale, shift); }
+// dx = gg * sc + x * ca + cb  with  ca = -sc * k2 * invstd,  cb = sc * (mean * invstd * k2 - k1),  k1 = sum(g) / m,  k2 = sum(g * xhat) / m
+__device__ __forceinline__ void bn_bwd_coef(const float sc, const float mean, const float is, const float sum_gx, const float sum_g, const float inv_m,
+                                            float& ca, float& cb) {
+#pragma clang fp contract(off)
+    const float k1 = sum_g * inv_m, k2 = sum_gx * inv_m;
+    const float mi = mean * is;
+    ca = -sc * k2 * is;
+    cb = sc * __builtin_fmaf(mi, k2, -k1);
+}
+__device__ __forceinline__ float bn_bwd_dx(const float gg, const float sc, const float x, const float ca, const float cb) {
+    return __builtin_fmaf(gg, sc, __builtin_fmaf(x, ca, cb));
+}

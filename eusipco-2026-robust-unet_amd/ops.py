@@ -474,11 +474,15 @@ def _conv_x3(mode, x, w_hwio, bias, out, n, h, w, cin, cout, accumulate, stats=N
     return out
 
 
-def conv_fwd(x, w_hwio, bias=None, out=None, dil=1, accumulate=False, keep_v=None, stats=None):
+def conv_fwd(x, w_hwio, bias=None, out=None, dil=1, accumulate=False, keep_v=None, stats=None, pre=None):
     """stats: dict; when the kernel that serves this convolution can take the BatchNorm statistics of its output in its epilogue it fills
-    stats["part"] / stats["nparts"] (blocks.bn_coeff(fused=stats) then skips its pass over the tensor), otherwise leaves it empty."""
+    stats["part"] / stats["nparts"] (blocks.bn_coeff(fused=stats) then skips its pass over the tensor), otherwise leaves it empty.
+    pre = (scale, shift, factor_nc or None), only where fuses_act_input(x, w_hwio): the convolution of max(x * scale + shift, 0) * factor."""
     n, h, w, cin = x.shape
     kh, kw, cin_w, cout = w_hwio.shape
+    if pre is not None:
+        assert fuses_act_input(x, w_hwio) and dil == 1
+        return wino4_conv(x, wino4_weights(w_hwio), bias, out=out, accumulate=accumulate, keep_v=keep_v, dil=dil, pre=pre)
     if _bf16_case(cin, cin_w):
         if out is None:
             out = empty_nhwc(n, h, w, cout, x)
@@ -550,11 +554,36 @@ def wino_ok(h, w, cin, cout):
     return bool(lib.runet_wino_supported(h, w, cin, cout))
 
 
-def conv_dgrad(dy, w_hwio, out=None, dil=1, accumulate=False, keep_z=None):
-    """keep_z: dict that receives {"Z": ...} when the layer takes the adjoint F(4x4) path - hand it to conv_wgrad(..., z=...) of the same layer."""
+# BatchNorm + ReLU (+ Dropout2d) folded into the loads of the F(4x4) input transforms (csrc/conv_winograd4.hip W4Pre): the activation in front
+# of a ResidualBlock's conv2 and the BatchNorm-backward dx in front of conv1's gradients are never written.  RUNET_NO_FUSED_BN_INPUT=1: two steps.
+FUSE_BN_INPUT = os.environ.get("RUNET_NO_FUSED_BN_INPUT", "0") != "1"
+
+
+def fuses_act_input(t, w_hwio):
+    """conv_fwd(t, w, pre=(scale, shift, factor)) is available: the 3x3 convolution takes the unfused F(4x4) path in fp32."""
+    n, h, w, cin = t.shape
+    kh, kw, cin_w, cout = w_hwio.shape
+    return FUSE_BN_INPUT and not _bf16_case(cin, cin_w) and _wino4_case(h, w, kh, 1, cin, cout, cin_w)
+
+
+def fuses_bn_bwd_input(dy, w_hwio):
+    """conv_dgrad(dy, w, keep_z=..., bn=...) is available: the data gradient takes the adjoint F(4x4) path (Z shared with the weight gradient)."""
+    n, h, w, cout = dy.shape
+    kh, kw, cin, cout_w = w_hwio.shape
+    return (FUSE_BN_INPUT and cout_w == cout and not _bf16_case(cout, cout) and _wino4_case(h, w, kh, 1, cout, cin, cout) and USE_W4_ADJOINT
+            and _x3_case(cout) and cin >= 16)
+
+
+def conv_dgrad(dy, w_hwio, out=None, dil=1, accumulate=False, keep_z=None, bn=None):
+    """keep_z: dict that receives {"Z": ...} when the layer takes the adjoint F(4x4) path - hand it to conv_wgrad(..., z=...) of the same layer.
+    bn = dict(x, mean, invstd, scale, shift, sums, m_total, mask), only where fuses_bn_bwd_input(dy, w_hwio): the data gradient of
+    blocks.bn_bwd_apply(dy, x, ..., relu_shift=shift) without that tensor being written; the weight gradient must then take keep_z's Z."""
     n, h, w, cout = dy.shape
     kh, kw, cin, cout_w = w_hwio.shape
     assert cout_w == cout
+    if bn is not None:
+        assert fuses_bn_bwd_input(dy, w_hwio) and dil == 1 and keep_z is not None
+        return wino4_dgrad_adj(dy, w_hwio, out=out, accumulate=accumulate, dil=dil, keep_z=keep_z, bn=bn)
     if _bf16_case(cout, cout):
         if out is None:
             out = empty_nhwc(n, h, w, cin, dy)
@@ -1038,9 +1067,9 @@ def wino4_weights(w_hwio, dgrad=False, adjoint=False):
     return _cached(w_hwio, "wino4d" if dgrad else "wino4", make)
 
 
-def wino4_conv(x, U, bias=None, out=None, accumulate=False, keep_v=None, dil=1):
+def wino4_conv(x, U, bias=None, out=None, accumulate=False, keep_v=None, dil=1, pre=None):
     """keep_v: dict that receives {"V": transformed input [36*T*K]} - the weight gradient of the same convolution reuses it
-    (conv_wgrad(..., v=...)) instead of transforming x again."""
+    (conv_wgrad(..., v=...)) instead of transforming x again.  pre: see conv_fwd."""
     n, h, w, k = x.shape
     x3 = U.dtype == torch.bfloat16                      # split-plane packing (wino4_weights under USE_X3)
     nn_ = U.kn[1] if x3 else U.shape[2]
@@ -1048,7 +1077,7 @@ def wino4_conv(x, U, bias=None, out=None, accumulate=False, keep_v=None, dil=1):
         out = empty_nhwc(n, h, w, nn_, x)
     bp = bias.data_ptr() if bias is not None else None
     t = n * (h // 4) * (w // 4)
-    if _PROFILE is None and keep_v is None:
+    if _PROFILE is None and keep_v is None and pre is None:
         ws = _workspace4(lib.runet_wino4_workspace_floats(n, h, w, k, nn_), x.device)
         fn = lib.runet_wino4_conv_x3 if x3 else lib.runet_wino4_conv
         check(fn(x.data_ptr(), ld(x), U.data_ptr(), bp, out.data_ptr(), ld(out), n, h, w, k, nn_, dil, int(accumulate), ws.data_ptr(),
@@ -1062,7 +1091,12 @@ def wino4_conv(x, U, bias=None, out=None, accumulate=False, keep_v=None, dil=1):
     else:
         ws = _workspace4(36 * t * (k + nn_), x.device)
         V, M = ws.data_ptr(), ws.data_ptr() + 4 * 36 * t * k
-    check(lib.runet_wino4_input(x.data_ptr(), ld(x), k, n, h, w, dil, 0, V, stream()))
+    if pre is None:
+        check(lib.runet_wino4_input(x.data_ptr(), ld(x), k, n, h, w, dil, 0, V, stream()))
+    else:
+        sc, sh, fac = pre
+        check(lib.runet_wino4_input_act(x.data_ptr(), ld(x), k, n, h, w, dil, sc.data_ptr(), sh.data_ptr(), fac.data_ptr() if fac is not None else None,
+                                        V, stream()))
     if _PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -1079,7 +1113,7 @@ def wino4_conv(x, U, bias=None, out=None, accumulate=False, keep_v=None, dil=1):
     return out
 
 
-def wino4_dgrad_adj(dy, w_hwio, out=None, accumulate=False, dil=1, keep_z=None):
+def wino4_dgrad_adj(dy, w_hwio, out=None, accumulate=False, dil=1, keep_z=None, bn=None):
     """Data gradient of conv3x3(x, w) by the adjoint form.  keep_z: dict that receives {"Z": A dy A^T [36*T*cout]} for the weight gradient of
     the same layer (conv_wgrad(..., z=...))."""
     n, h, w, cout = dy.shape
@@ -1095,7 +1129,13 @@ def wino4_dgrad_adj(dy, w_hwio, out=None, accumulate=False, dil=1, keep_z=None):
     else:
         ws = _workspace4(36 * t * (cout + cin), dy.device)
         Z, M = ws.data_ptr(), ws.data_ptr() + 4 * 36 * t * cout
-    check(lib.runet_wino4_input(dy.data_ptr(), ld(dy), cout, n, h, w, dil, 1, Z, stream()))
+    if bn is None:
+        check(lib.runet_wino4_input(dy.data_ptr(), ld(dy), cout, n, h, w, dil, 1, Z, stream()))
+    else:
+        bx, mk = bn["x"], bn.get("mask")
+        check(lib.runet_wino4_input_bn_bwd(dy.data_ptr(), ld(dy), bx.data_ptr(), ld(bx), cout, n, h, w, dil, bn["mean"].data_ptr(), bn["invstd"].data_ptr(),
+                                           bn["scale"].data_ptr(), bn["shift"].data_ptr(), bn["sums"].data_ptr(), mk.data_ptr() if mk is not None else None,
+                                           int(bn["m_total"]), Z, stream()))
     if _PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

@@ -314,6 +314,16 @@ int runet_wino4_conv_x3(const float* x, int ldx, const void* Upacked, const floa
  *   runet_gemm_batched / runet_gemm_tn_batched: the 36 position-GEMMs
  *   runet_wino4_output: y = A^T M A (+bias, +y);  runet_wino4_wgrad_output: dw[3][3][cin][cout] = G^T (sum_splits dU[split][36][cin][cout]) G */
 int runet_wino4_input(const float* src, int ld, int c, int n_img, int h, int w, int dil, int mode, float* V, void* stream);
+/* The same transforms with their input's elementwise producer folded into the loads (the tensor between the two is never written; results
+ * bit-identical to the two-step forms).  runet_wino4_input_act: mode 0 of a1 = runet_bn_apply(t, scale, shift, factor_nc, relu = 1), i.e. the
+ * BatchNorm + ReLU + Dropout2d in front of a ResidualBlock's conv2 (Main_Final.py:157-160).  runet_wino4_input_bn_bwd: mode 1 of
+ * dx = runet_bn_bwd_apply(dy, x, ..., relu_shift = shift), i.e. autograd's backward of that BatchNorm + ReLU feeding conv1's gradients; sums as
+ * runet_bn_bwd_reduce leaves them, m_total 0 = the tensor's own pixel count. */
+int runet_wino4_input_act(const float* t, int ld, int c, int n_img, int h, int w, int dil, const float* scale, const float* shift,
+                          const float* factor_nc, float* V, void* stream);
+int runet_wino4_input_bn_bwd(const float* dy, int lddy, const float* x, int ldx, int c, int n_img, int h, int w, int dil, const float* mean,
+                             const float* invstd, const float* scale, const float* shift, const float* sums, const float* factor_nc,
+                             long m_total, float* Z, void* stream);
 int runet_wino4_output(const float* M, int n, int n_img, int h, int w, int dil, const float* bias, float* y, int ldy, int accumulate, void* stream);
 /* The data gradient as the ADJOINT of the forward algorithm: Z = A dy A^T (runet_wino4_input mode 1 - the weight gradient's transform, shared),
  * M' = Z . U^T by the position GEMMs (runet_wino4_weights_x3 with dgrad = 2: the forward's U transposed, not rotated), and this gather-form

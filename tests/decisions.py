@@ -199,7 +199,7 @@ def hip_step(model, x, y, dev=None):
         for k in RB:     # copies: the backward reuses some of these buffers in place
             c = C[k]
             n, h, w, ch = c["out"].shape
-            dec["act"][k] = dict(a1=nchw(c["a1"]), out=nchw(c["out"]))
+            dec["act"][k] = dict(a1=nchw(blocks.rb_a1(c)), out=nchw(c["out"]))
             dec["sa"][k] = c["amax"].detach().cpu().long().reshape(n, h, w)
             dec["ca"][k] = c["idx"].detach().cpu().long().reshape(n, ch)
         dec["act"]["bottleneck.1"] = dict(out=nchw(C["bottleneck.1"]["out"]))
