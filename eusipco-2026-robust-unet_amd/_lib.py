@@ -26,7 +26,8 @@ if _HW_QUEUES_LATE:
                   "Import the package (or export GPU_MAX_HW_QUEUES=8) before the first CUDA/HIP call.", RuntimeWarning, stacklevel=2)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "librunet_hip.so")
+# RUNET_HIP_LIB: another build of the same library (A/B of two builds inside one GPU call); there is still no fallback if it is missing
+LIB_PATH = os.environ.get("RUNET_HIP_LIB") or os.path.join(_HERE, "csrc", "librunet_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "runet_hip.h")
 
 _SCALARS = {"int": C.c_int, "long": C.c_long, "float": C.c_float, "double": C.c_double, "void": None}

@@ -34,7 +34,6 @@ struct WinoX3Args {
     int accumulate;
     int npatches, nchunks;        // grid = npatches * nchunks blocks (4x8-tile patches x 64-channel output chunks)
     float* stats;                 // nullptr, or [npatches][N][3]: (count, mean, M2) per output channel over the block's pixels (BatchNorm statistics)
-    int abl;                      // timing ablations (wrong results): 1 = every filter fragment read from the first position / chunk (L1-resident), 2 = no operand split (one plane stored), 4 = no MFMAs, 8 = transform phase skipped
 };
 
 constexpr int WT = 32;            // tiles per block
@@ -101,10 +100,6 @@ __global__ __launch_bounds__(256, 2) void wino_conv_x3_kernel(WinoX3Args g) {
     const int rbase = ((2 * (lt >> 3)) * RW + 2 * (lt & 7)) * RPS + 2 * k2;
     const int vbase = (lt * 2 + ((k2 >> 2) ^ ((lt >> 3) & 1))) * 16 + (k2 & 3) * 4;      // bytes inside a position's [32 tiles][32 B] image
     auto put = [&](int xi, const float2 v) {
-        if (g.abl & 2) {          // timing ablation: no operand split, one plane stored
-            *reinterpret_cast<bf16x2*>(Vp + xi * (WT * 32) + vbase) = bf16x2{(__bf16)v.x, (__bf16)v.y};
-            return;
-        }
         const bf16x2 h = {(__bf16)v.x, (__bf16)v.y};
         const float rx = v.x - (float)h[0], ry = v.y - (float)h[1];
         const bf16x2 m = {(__bf16)rx, (__bf16)ry};
@@ -157,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void wino_conv_x3_kernel(WinoX3Args g) {
     auto load_step = [&](int t, int c0, bf16x8 (&slot)[3]) {
         const int xi = wid * 4 + (t >> 1);
 #pragma unroll
-        for (int p = 0; p < 3; ++p) slot[p] = U16[(g.abl & 1 ? 0L : (long)((xi * 3 + p) * K8 + (c0 >> 3)) * g.N) + uoff[t & 1]];      // scalar base + lane offset
+        for (int p = 0; p < 3; ++p) slot[p] = U16[(long)((xi * 3 + p) * K8 + (c0 >> 3)) * g.N + uoff[t & 1]];      // scalar base + lane offset
     };
     const int a_rd = (li * 2 + (lh ^ ((li >> 3) & 1))) * 16;
     auto read_a = [&](int xl, bf16x8 (&a)[3]) {
@@ -174,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void wino_conv_x3_kernel(WinoX3Args g) {
         const int cn = (ch + 1 < nchunks) ? c0 + 16 : c0;      // last chunk: harmless re-read, keeps the code branch-free
         store_halo();                          // R was last read before the previous chunk's second barrier
         __syncthreads();                       // R complete; previous chunk's MFMA reads of V are done
-        if (!(g.abl & 8)) transform_store();
+        transform_store();
         __syncthreads();
         bf16x8 af[2][3];
         read_a(0, af[0]);
@@ -185,8 +180,7 @@ __global__ __launch_bounds__(256, 2) void wino_conv_x3_kernel(WinoX3Args g) {
             if (t == 1) load_halo(cn);                                 // next chunk's halo: in flight during the rest of the MFMAs
             if ((t & 1) == 0 && t + 2 < 8) read_a((t >> 1) + 1, af[((t >> 1) + 1) & 1]);      // next position's A fragments
             __builtin_amdgcn_sched_barrier(0);
-            if (!(g.abl & 4)) X3_MMA(acc[t >> 1][t & 1], af[(t >> 1) & 1], ring[t & 3]);      // abl 4: no MFMAs
-            else acc[t >> 1][t & 1][0] += (float)af[(t >> 1) & 1][0][0] * (float)ring[t & 3][0][0];
+            X3_MMA(acc[t >> 1][t & 1], af[(t >> 1) & 1], ring[t & 3]);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -341,8 +335,6 @@ static int wino_conv_x3_launch(const float* x, int ldx, const void* Upacked, con
     a.Nimg = n_img; a.H = h; a.W = w; a.TY = h / 2; a.TX = w / 2; a.accumulate = accumulate;
     a.npatches = n_img * cdiv(a.TY, 4) * cdiv(a.TX, 8);
     a.nchunks = cdiv(n, WBN);
-    static const int abl = getenv("RUNET_WINO_X3_ABL") ? atoi(getenv("RUNET_WINO_X3_ABL")) : 0;      // timing ablations only (wrong results)
-    a.abl = abl;
     a.stats = stats;
     hipLaunchKernelGGL(wino_conv_x3_kernel, dim3(a.npatches * a.nchunks), dim3(256), 0, (hipStream_t)stream, a);
     RUNET_CHECK_LAUNCH();

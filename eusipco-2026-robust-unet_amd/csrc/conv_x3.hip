@@ -177,13 +177,23 @@ __global__ __launch_bounds__(256, 2) void conv_nn_x3_kernel(X3ConvArgs g) {
             for (int b = 0; b < TN; ++b) X3_MMA(acc[a][b], af[a], bf[b]);
         store_tile(nx2, cur_set);
         lds_barrier();
+        __builtin_amdgcn_sched_barrier(0);      // keep the next step's split / stores from being hoisted over this one (they would pull its vmcnt wait forward)
         cur = nxt;
     };
-    for (int s = 0; s < nks; s += 4) {
+    // four unconditional steps per trip (see gemm_split.hip: a conditional step inside the loop makes the compiler drain vmcnt at the header)
+    int s = 0;
+    for (; s + 4 <= nks; s += 4) {
         step(R2, R1);
-        if (s + 1 < nks) step(R3, R2);
-        if (s + 2 < nks) step(R0, R3);
-        if (s + 3 < nks) step(R1, R0);
+        step(R3, R2);
+        step(R0, R3);
+        step(R1, R0);
+    }
+    if (s < nks) {
+        step(R2, R1);
+        if (s + 1 < nks) {
+            step(R3, R2);
+            if (s + 2 < nks) step(R0, R3);
+        }
     }
 
     // ---- epilogue: lane holds column li of each 32-wide tile, rows (r&3) + 8*(r>>2) + 4*lh

@@ -167,13 +167,25 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_x3_kernel(X3Args g) {
             for (int b = 0; b < TN; ++b) X3_MMA(acc[a][b], af[a], bf[b]);
         store_tile(nx2, cur_set);
         lds_barrier();
+        __builtin_amdgcn_sched_barrier(0);      // keep the next step's split / stores from being hoisted over this one (they would pull its vmcnt wait forward)
         cur = nxt;
     };
-    for (int s = 0; s < nks; s += 4) {
+    // Four UNCONDITIONAL steps per trip: with `if (s + 1 < nks) step(...)` inside the loop the CFG has a path header -> step 0 -> latch -> header
+    // on which step 0's loads are still in flight when the header's LDS reads reuse their registers, and the compiler's s_waitcnt insertion
+    // (conservative over all paths) drained vmcnt to 0 at every fourth step - the four-deep prefetch never got more than one step deep there.
+    int s = 0;
+    for (; s + 4 <= nks; s += 4) {
         step(s, R2, R1);
-        if (s + 1 < nks) step(s + 1, R3, R2);
-        if (s + 2 < nks) step(s + 2, R0, R3);
-        if (s + 3 < nks) step(s + 3, R1, R0);
+        step(s + 1, R3, R2);
+        step(s + 2, R0, R3);
+        step(s + 3, R1, R0);
+    }
+    if (s < nks) {                                      // k not a multiple of 64: up to three more
+        step(s, R2, R1);
+        if (s + 1 < nks) {
+            step(s + 1, R3, R2);
+            if (s + 2 < nks) step(s + 2, R0, R3);
+        }
     }
 
     // ---- epilogue: lane holds column li of each 32-wide tile, rows (r&3) + 8*(r>>2) + 4*lh
@@ -333,13 +345,25 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(X3Args g) {
             for (int b = 0; b < 2; ++b) X3_MMA(acc[a][b], af[a], bf[b]);
         store_tile(nx2, cur_set);
         lds_barrier();
+        __builtin_amdgcn_sched_barrier(0);      // keep the next step's split / stores from being hoisted over this one (they would pull its vmcnt wait forward)
         cur = nxt;
     };
-    for (int s = 0; s < nks; s += 4) {
+    // Four UNCONDITIONAL steps per trip: with `if (s + 1 < nks) step(...)` inside the loop the CFG has a path header -> step 0 -> latch -> header
+    // on which step 0's loads are still in flight when the header's LDS reads reuse their registers, and the compiler's s_waitcnt insertion
+    // (conservative over all paths) drained vmcnt to 0 at every fourth step - the four-deep prefetch never got more than one step deep there.
+    int s = 0;
+    for (; s + 4 <= nks; s += 4) {
         step(s, R2, R1);
-        if (s + 1 < nks) step(s + 1, R3, R2);
-        if (s + 2 < nks) step(s + 2, R0, R3);
-        if (s + 3 < nks) step(s + 3, R1, R0);
+        step(s + 1, R3, R2);
+        step(s + 2, R0, R3);
+        step(s + 3, R1, R0);
+    }
+    if (s < nks) {                                      // k not a multiple of 64: up to three more
+        step(s, R2, R1);
+        if (s + 1 < nks) {
+            step(s + 1, R3, R2);
+            if (s + 2 < nks) step(s + 2, R0, R3);
+        }
     }
 
     float* Cs = g.c + ((long)blockIdx.y * g.gz + z) * g.k * g.n;
