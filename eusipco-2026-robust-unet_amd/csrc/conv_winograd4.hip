@@ -213,6 +213,33 @@ __global__ __launch_bounds__(256) void wino4_output_adj_kernel(const float* __re
     const long xs = g.T * N;
     const float* in = M + tile * N + c;
     auto ld = [&](const float* base, int pos) { return *reinterpret_cast<const f32x2*>(base + (long)pos * xs); };
+    const bool up = ty > 0, down = ty < g.TY - 1, left = tx > 0, right = tx < g.TX - 1;
+    const long dT = (long)g.TX * N;                      // one tile row
+    // All 28 neighbour values are loaded up front from clamped addresses (a missing neighbour reads this tile's own patch and is discarded):
+    // one batch of loads in flight instead of eight dependent load -> wait -> add groups.
+    const float* qu = up ? in - dT : in;
+    const float* qd = down ? in + dT : in;
+    const float* ql = left ? in - N : in;
+    const float* qr = right ? in + N : in;
+    f32x2 nu[6], nd[6], nl[6], nr[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        nu[k] = ld(qu, 30 + k);                          // row 5 of the tile above
+        nd[k] = ld(qd, k);                               // row 0 of the tile below
+        nl[k] = ld(ql, 6 * k + 5);                       // column 5 of the tile to the left
+        nr[k] = ld(qr, 6 * k);                           // column 0 of the tile to the right
+    }
+    const f32x2 cul = ld(up && left ? in - dT - N : in, 35), cur = ld(up && right ? in - dT + N : in, 30);
+    const f32x2 cdl = ld(down && left ? in + dT - N : in, 5), cdr = ld(down && right ? in + dT + N : in, 0);
+    float* dst = y + pix(g, n, 4 * ty, 4 * tx) * ldy + c;
+    const long rs = (long)g.D * g.WF * ldy, ps = (long)g.D * ldy;
+    f32x2 old[4][4];
+    if (accumulate) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) old[i][j] = *reinterpret_cast<const f32x2*>(dst + i * rs + j * ps);
+    }
     // own patch: columns first (B applied down each column), then rows; only the inner 4 x 4 is used
     f32x2 t[6][6];
 #pragma unroll
@@ -230,53 +257,35 @@ __global__ __launch_bounds__(256) void wino4_output_adj_kernel(const float* __re
 #pragma unroll
         for (int j = 1; j < 5; ++j) out[i - 1][j - 1] = o[j];
     }
-    const bool up = ty > 0, down = ty < g.TY - 1, left = tx > 0, right = tx < g.TX - 1;
-    const long dT = (long)g.TX * N;                      // one tile row
-    // vertical neighbours: their row 5 (tile above) / 4 x row 0 (tile below), transformed along the row
-    if (up) {
-        const float* q = in - dT;
+    const f32x2 zero = {0.f, 0.f};
+    {   // vertical neighbours: their row 5 (tile above) / 4 x row 0 (tile below), transformed along the row
         f32x2 o[6];
-        b6(ld(q, 30), ld(q, 31), ld(q, 32), ld(q, 33), ld(q, 34), ld(q, 35), o);
+        b6(nu[0], nu[1], nu[2], nu[3], nu[4], nu[5], o);
 #pragma unroll
-        for (int j = 1; j < 5; ++j) out[0][j - 1] += o[j];
-    }
-    if (down) {
-        const float* q = in + dT;
-        f32x2 o[6];
-        b6(ld(q, 0), ld(q, 1), ld(q, 2), ld(q, 3), ld(q, 4), ld(q, 5), o);
+        for (int j = 1; j < 5; ++j) out[0][j - 1] += up ? o[j] : zero;
+        b6(nd[0], nd[1], nd[2], nd[3], nd[4], nd[5], o);
 #pragma unroll
-        for (int j = 1; j < 5; ++j) out[3][j - 1] += 4.f * o[j];
-    }
-    // horizontal neighbours: their column 5 (tile to the left) / 4 x column 0 (tile to the right), transformed along the column
-    if (left) {
-        const float* q = in - N;
-        f32x2 o[6];
-        b6(ld(q, 5), ld(q, 11), ld(q, 17), ld(q, 23), ld(q, 29), ld(q, 35), o);
+        for (int j = 1; j < 5; ++j) out[3][j - 1] += down ? 4.f * o[j] : zero;
+        // horizontal neighbours: their column 5 (tile to the left) / 4 x column 0 (tile to the right), transformed along the column
+        b6(nl[0], nl[1], nl[2], nl[3], nl[4], nl[5], o);
 #pragma unroll
-        for (int i = 1; i < 5; ++i) out[i - 1][0] += o[i];
-    }
-    if (right) {
-        const float* q = in + N;
-        f32x2 o[6];
-        b6(ld(q, 0), ld(q, 6), ld(q, 12), ld(q, 18), ld(q, 24), ld(q, 30), o);
+        for (int i = 1; i < 5; ++i) out[i - 1][0] += left ? o[i] : zero;
+        b6(nr[0], nr[1], nr[2], nr[3], nr[4], nr[5], o);
 #pragma unroll
-        for (int i = 1; i < 5; ++i) out[i - 1][3] += 4.f * o[i];
+        for (int i = 1; i < 5; ++i) out[i - 1][3] += right ? 4.f * o[i] : zero;
     }
     // diagonal neighbours: one corner value each
-    if (up && left) out[0][0] += ld(in - dT - N, 35);
-    if (up && right) out[0][3] += 4.f * ld(in - dT + N, 30);
-    if (down && left) out[3][0] += 4.f * ld(in + dT - N, 5);
-    if (down && right) out[3][3] += 16.f * ld(in + dT + N, 0);
-    float* dst = y + pix(g, n, 4 * ty, 4 * tx) * ldy + c;
-    const long rs = (long)g.D * g.WF * ldy, ps = (long)g.D * ldy;
+    out[0][0] += (up && left) ? cul : zero;
+    out[0][3] += (up && right) ? 4.f * cur : zero;
+    out[3][0] += (down && left) ? 4.f * cdl : zero;
+    out[3][3] += (down && right) ? 16.f * cdr : zero;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            float* p = dst + i * rs + j * ps;
             f32x2 v = out[i][j];
-            if (accumulate) v += *reinterpret_cast<const f32x2*>(p);
-            *reinterpret_cast<f32x2*>(p) = v;
+            if (accumulate) v += old[i][j];
+            *reinterpret_cast<f32x2*>(dst + i * rs + j * ps) = v;
         }
 }
 
@@ -336,8 +345,11 @@ __global__ __launch_bounds__(256) void wino4_wgrad_out_kernel(const float* __res
     for (int x = 0; x < 36; ++x) m[x] = 0.f;
     for (int s = 0; s < splits; ++s) {
         const float* p = dU + (long)s * 36 * kn + i;
+        float v[36];                           // all 36 loads of a split in flight before the first add (the fused form waited per pair of loads)
 #pragma unroll
-        for (int x = 0; x < 36; ++x) m[x] += p[(long)x * kn];
+        for (int x = 0; x < 36; ++x) v[x] = p[(long)x * kn];
+#pragma unroll
+        for (int x = 0; x < 36; ++x) m[x] += v[x];
     }
     float t[3][6];
 #pragma unroll

@@ -1,7 +1,9 @@
 // Cycles per MFMA (s_memtime over a back-to-back chain, one wave per SIMD): which bf16 shapes run at the full gfx950 rate.
 // build: /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o tools/micro/mfma_rate tools/micro/mfma_rate.hip ; run tools/micro/mfma_rate on the GPU box
 // measured (MI355X, ROCm 7.2; rotating over 4 / 16 accumulators): 16x16x16_bf16 (1k) 24.6 / 29.1 | 16x16x32_bf16 24.2 / 28.9 | 32x32x16_bf16 32.8 / 33.6 |
-// 16x16x4_f32 33.1 / 33.8 | 32x32x8_bf16 (1k) 33.0 / 33.8 cycles per MFMA: the legacy K = 16 / 8 bf16 forms cost what the K = 32 / 16 forms cost
+// 16x16x4_f32 33.1 / 33.8 | 32x32x8_bf16 (1k) 33.0 / 33.8 cycles per MFMA: the legacy K = 16 / 8 bf16 forms cost what the K = 32 / 16 forms cost.
+// A chain of 32x32x16_bf16 on ONE accumulator (each MFMA's C = the previous one's D): 32.4 - dependent accumulation issues back to back, so the
+// six products of X3_MMA need no interleaving across accumulators.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
