@@ -30,10 +30,15 @@ ROOT=$(pwd)
 ( cd /tmp && export TMPDIR=/tmp && RUNET_NO_WGRAD_STREAM=1 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$O/ss_trace -- python3 $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > /dev/null 2>&1 )
 python3 tools/prof_summary.py $O/ss_trace 13 > $O/${TAG}_kernel_stats_single_stream.txt
 cp $(ls $O/ss_trace/*/*kernel_stats.csv | head -1) $O/${TAG}_kernel_stats_single_stream.csv
+python3 tools/step_sequence.py $O/ss_trace > $O/${TAG}_step_sequence.txt
 rm -rf $O/ss_trace
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --output-format csv -d $ROOT/$O/gap_trace -- python3 $ROOT/bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-roofline > /dev/null 2>&1 )
 python3 tools/trace_gaps.py $O/gap_trace 0.5 > $O/${TAG}_trace_gaps.txt
 rm -rf $O/gap_trace
+( cd /tmp && export TMPDIR=/tmp && RUNET_NO_WGRAD_STREAM=1 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$O/b2_trace -- python3 $ROOT/bench.py --batch 2 --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > /dev/null 2>&1 )
+python3 tools/prof_summary.py $O/b2_trace 13 > $O/${TAG}_kernel_stats_batch2.txt
+python3 tools/step_sequence.py $O/b2_trace | head -1 >> $O/${TAG}_kernel_stats_batch2.txt
+rm -rf $O/b2_trace
 echo traces done
 python tools/conv_launches.py > $O/${TAG}_conv_launches.txt 2>/dev/null
 python tools/conv_launches.py --dtype bf16 > $O/${TAG}_bf16_conv_launches.txt 2>/dev/null
