@@ -9,6 +9,15 @@ namespace derive {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+__device__ __forceinline__ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// gm[0..7][r][q] = p[0..7] by two 16-byte loads (p 16-byte aligned)
+__device__ __forceinline__ void load8(const float* __restrict__ p, float (&gm)[8][3][3], const int r, const int q) {
+    const f32x4 a = reinterpret_cast<const f32x4*>(p)[0], b = reinterpret_cast<const f32x4*>(p)[1];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { gm[j][r][q] = a[j]; gm[4 + j][r][q] = b[j]; }
+}
+
 __device__ __forceinline__ void store_split(const float (&u)[8], __bf16* d, const long plane) {
     bf16x8 h, m, l;
 #pragma unroll
@@ -35,15 +44,27 @@ __device__ __forceinline__ void wino4_weight_x3_body(const float* __restrict__ w
     if (i >= per) return;
     const int oc = (int)(i / N), n = (int)(i - (long)oc * N);
     float gm[8][3][3];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int k = oc * 8 + j;
+    if (dgrad && aligned16(w)) {
+        // transposed modes: the thread's eight k are contiguous in w (k = output channel, innermost) - two 16-byte loads per tap instead of
+        // eight 4-byte loads that each touch 64 different 32-byte sectors per wave
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
-            for (int q = 0; q < 3; ++q)
-                gm[j][r][q] = dgrad == 1 ? w[((long)((2 - r) * 3 + (2 - q)) * cin + n) * cout + k]
-                            : dgrad == 2 ? w[((long)(r * 3 + q) * cin + n) * cout + k] : w[((long)(r * 3 + q) * cin + k) * cout + n];
+            for (int q = 0; q < 3; ++q) {
+                const int tap = dgrad == 1 ? (2 - r) * 3 + (2 - q) : r * 3 + q;
+                load8(w + ((long)tap * cin + n) * cout + oc * 8, gm, r, q);
+            }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = oc * 8 + j;
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    gm[j][r][q] = dgrad == 1 ? w[((long)((2 - r) * 3 + (2 - q)) * cin + n) * cout + k]
+                                : dgrad == 2 ? w[((long)(r * 3 + q) * cin + n) * cout + k] : w[((long)(r * 3 + q) * cin + k) * cout + n];
+        }
     }
     auto grow = [](const float g0, const float g1, const float g2, const int a) -> float {      // row a of G applied to (g0, g1, g2)
         const float e = (g0 + g2) * (1.f / 6.f), f = g0 * (1.f / 24.f) + g2 * (1.f / 6.f);
@@ -80,14 +101,21 @@ __device__ __forceinline__ void wino_weight_x3_body(const float* __restrict__ w,
     if (i >= per) return;
     const int oc = (int)(i / N), n = (int)(i - (long)oc * N);
     float gm[8][3][3];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int k = oc * 8 + j;
+    if (dgrad && aligned16(w)) {
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
-            for (int q = 0; q < 3; ++q)
-                gm[j][r][q] = dgrad ? w[((long)((2 - r) * 3 + (2 - q)) * cin + n) * cout + k] : w[((long)(r * 3 + q) * cin + k) * cout + n];
+            for (int q = 0; q < 3; ++q) load8(w + ((long)((2 - r) * 3 + (2 - q)) * cin + n) * cout + oc * 8, gm, r, q);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = oc * 8 + j;
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    gm[j][r][q] = dgrad ? w[((long)((2 - r) * 3 + (2 - q)) * cin + n) * cout + k] : w[((long)(r * 3 + q) * cin + k) * cout + n];
+        }
     }
     auto grow = [](const float g0, const float g1, const float g2, const int a) -> float {      // row a of G = [1,0,0; .5,.5,.5; .5,-.5,.5; 0,0,1]
         switch (a) {
@@ -124,8 +152,14 @@ __device__ __forceinline__ void pack_x3_body(const float* __restrict__ w, long s
     const int oc = (int)(r / n), col = (int)(r - (long)oc * n);
     const float* s = w + (long)z * stride_z + (long)oc * 8 * sk + (long)col * sn;
     float u[8];
+    if (sk == 1 && aligned16(s)) {               // transposed modes: eight contiguous floats
+        const f32x4 a = reinterpret_cast<const f32x4*>(s)[0], b = reinterpret_cast<const f32x4*>(s)[1];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) u[j] = s[(long)j * sk];
+        for (int j = 0; j < 4; ++j) { u[j] = a[j]; u[4 + j] = b[j]; }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) u[j] = s[(long)j * sk];
+    }
     store_split(u, dst + (long)z * 3 * per * 8 + r * 8, per * 8);
 }
 
