@@ -33,7 +33,10 @@ def main():
         red.broadcast_parameters(0)                                   # brings the communicator up before any capture
         step = trainer.TrainStep(m, lr=1e-3, weight_decay=1e-4, grad_sync=red, graph=graph, graph_warmup=2)
         step.optimizer.capturable = True
-        losses = [step(x.to(dev), y.to(dev)).detach().clone() for x, y in batches]
+        losses = []
+        for i, (x, y) in enumerate(batches):
+            losses.append(step(x.to(dev), y.to(dev)).detach().clone())
+            print(f"graph={graph} step {i} done (captured: {getattr(step, '_graph', None) is not None})", file=sys.stderr, flush=True)
         torch.cuda.synchronize()
         assert len(red.buckets_last_step) >= 3, red.buckets_last_step
         if graph:

@@ -10,10 +10,11 @@ frac = float(sys.argv[2]) if len(sys.argv) > 2 else 0.4
 rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(f))), key=lambda r: r[0])
 rows = rows[int(len(rows) * (1 - frac)):]
 span = rows[-1][1] - rows[0][0]
-busy, cur_end, gaps, overl = 0, rows[0][0], [], 0
-for s, e, _ in rows:
+busy, cur_end, gaps, overl, where, last = 0, rows[0][0], [], 0, [], ""
+for s, e, name in rows:
     if s > cur_end:
         gaps.append(s - cur_end)
+        where.append((s - cur_end, last, name, s - rows[0][0]))
         busy += e - s
         cur_end = e
     else:
@@ -21,6 +22,8 @@ for s, e, _ in rows:
         if e > cur_end:
             busy += e - cur_end
             cur_end = e
+    if e >= cur_end:
+        last = name
 ksum = sum(e - s for s, e, _ in rows)
 gaps.sort()
 print(f"{len(rows)} dispatches, span {span / 1e6:.2f} ms, summed kernel time {ksum / 1e6:.2f} ms, >=1 kernel running {busy / 1e6:.2f} ms "
@@ -28,3 +31,7 @@ print(f"{len(rows)} dispatches, span {span / 1e6:.2f} ms, summed kernel time {ks
 if gaps:
     q = lambda p: gaps[min(len(gaps) - 1, int(p * len(gaps)))] / 1e3
     print(f"idle gaps: {len(gaps)}, total {sum(gaps) / 1e6:.2f} ms, median {q(0.5):.1f} us, p90 {q(0.9):.1f} us, max {gaps[-1] / 1e3:.1f} us")
+short = lambda n: n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:44]
+print("largest gaps (us, kernel that ended last before it -> kernel that started after it, offset in the window):")
+for g, a, b, off in sorted(where, reverse=True)[:16]:
+    print(f"   {g / 1e3:8.1f}  {short(a):44s} -> {short(b):44s} at {off / 1e6:8.2f} ms")
