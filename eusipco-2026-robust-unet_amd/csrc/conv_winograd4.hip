@@ -144,43 +144,93 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restric
         for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x2*>(out + (long)(i * 6 + j) * xs) = d[i][j];
 }
 
+// STATS: the BatchNorm statistics of what is stored ride along - (count, mean, M2) of the thread's 16 pixels per channel by a two-pass in
+// registers, Chan-combined in tile order over the tiles of the block that hold the same channel pair (N/2 a power of two <= 256: 256 / (N/2)
+// tiles per block, one partial row per block; N/2 >= 256: one row per tile).  stats [wino4_stats_parts][N][3]; fixed order: reproducible.
+template <bool STATS>
 __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restrict__ M, int N, W4Geom g, const float* __restrict__ bias,
-                                                           float* __restrict__ y, int ldy, int accumulate) {
+                                                           float* __restrict__ y, int ldy, int accumulate, float* __restrict__ stats) {
     const int N2 = N >> 1;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= g.T * N2) return;
-    const long tile = idx / N2;
-    const int c = (int)(idx - tile * N2) * 2;
-    const int per = g.TY * g.TX;
-    const int n = (int)(tile / per);
-    const int rem = (int)(tile - (long)n * per);
-    const int ty = rem / g.TX, tx = rem - ty * g.TX;
-    const float* in = M + tile * N + c;
-    const long xs = g.T * N;
-    f32x2 s[4][6];
+    const bool valid = idx < g.T * N2;
+    if (!STATS && !valid) return;
+    const long tile = valid ? idx / N2 : 0;
+    const int c = valid ? (int)(idx - tile * N2) * 2 : 0;
+    f32x2 vals[4][4];
+    if (valid) {
+        const int per = g.TY * g.TX;
+        const int n = (int)(tile / per);
+        const int rem = (int)(tile - (long)n * per);
+        const int ty = rem / g.TX, tx = rem - ty * g.TX;
+        const float* in = M + tile * N + c;
+        const long xs = g.T * N;
+        f32x2 s[4][6];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        f32x2 m[6], o[4];
+        for (int j = 0; j < 6; ++j) {
+            f32x2 m[6], o[4];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) m[i] = *reinterpret_cast<const f32x2*>(in + (long)(i * 6 + j) * xs);
-        at4(m[0], m[1], m[2], m[3], m[4], m[5], o);
+            for (int i = 0; i < 6; ++i) m[i] = *reinterpret_cast<const f32x2*>(in + (long)(i * 6 + j) * xs);
+            at4(m[0], m[1], m[2], m[3], m[4], m[5], o);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) s[i][j] = o[i];
+            for (int i = 0; i < 4; ++i) s[i][j] = o[i];
+        }
+        f32x2 bv = {0.f, 0.f};
+        if (bias) bv = *reinterpret_cast<const f32x2*>(bias + c);
+        float* dst = y + pix(g, n, 4 * ty, 4 * tx) * ldy + c;
+        const long rs = (long)g.D * g.WF * ldy, ps = (long)g.D * ldy;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x2 o[4];
+            at4(s[i][0], s[i][1], s[i][2], s[i][3], s[i][4], s[i][5], o);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float* p = dst + i * rs + j * ps;
+                f32x2 v = o[j] + bv;
+                if (accumulate) v += *reinterpret_cast<const f32x2*>(p);
+                *reinterpret_cast<f32x2*>(p) = v;
+                vals[i][j] = v;
+            }
+        }
     }
-    f32x2 bv = {0.f, 0.f};
-    if (bias) bv = *reinterpret_cast<const f32x2*>(bias + c);
-    float* dst = y + pix(g, n, 4 * ty, 4 * tx) * ldy + c;
-    const long rs = (long)g.D * g.WF * ldy, ps = (long)g.D * ldy;
+    if constexpr (STATS) {
+        f32x2 mean = {0.f, 0.f}, m2 = {0.f, 0.f};
+        if (valid) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        f32x2 o[4];
-        at4(s[i][0], s[i][1], s[i][2], s[i][3], s[i][4], s[i][5], o);
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float* p = dst + i * rs + j * ps;
-            f32x2 v = o[j] + bv;
-            if (accumulate) v += *reinterpret_cast<const f32x2*>(p);
-            *reinterpret_cast<f32x2*>(p) = v;
+                for (int j = 0; j < 4; ++j) mean += vals[i][j];
+            mean *= (1.f / 16.f);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const f32x2 d = vals[i][j] - mean; m2 += d * d; }
+        }
+        if (N2 >= 256) {                          // one tile slice per block: the thread's pair is the only holder of its channels in row `tile`
+            if (valid) {
+                float* o = stats + (tile * N + c) * 3;
+                o[0] = 16.f; o[1] = mean[0]; o[2] = m2[0]; o[3] = 16.f; o[4] = mean[1]; o[5] = m2[1];
+            }
+            return;
+        }
+        __shared__ float sst[256 * 5];            // [thread][count, mean0, m2_0, mean1, m2_1]
+        float* me = sst + threadIdx.x * 5;
+        me[0] = valid ? 16.f : 0.f; me[1] = mean[0]; me[2] = m2[0]; me[3] = mean[1]; me[4] = m2[1];
+        __syncthreads();
+        if ((int)threadIdx.x < N2) {              // 256 % N2 == 0: thread t holds channel pair t of the block's first tile, t + N2 of the next, ...
+            float cnt = 0.f, mu0 = 0.f, q0 = 0.f, mu1 = 0.f, q1 = 0.f;
+            for (int t = threadIdx.x; t < 256; t += N2) {
+                const float* o = sst + t * 5;
+                const float nb = o[0];
+                if (nb > 0.f) {
+                    const float nt = cnt + nb, f = nb / nt, w = cnt * f;
+                    const float d0 = o[1] - mu0, d1 = o[3] - mu1;
+                    mu0 += d0 * f; q0 += o[2] + d0 * d0 * w;
+                    mu1 += d1 * f; q1 += o[4] + d1 * d1 * w;
+                    cnt = nt;
+                }
+            }
+            float* o = stats + ((long)blockIdx.x * N + 2 * threadIdx.x) * 3;
+            o[0] = cnt; o[1] = mu0; o[2] = q0; o[3] = cnt; o[4] = mu1; o[5] = q1;
         }
     }
 }
@@ -458,7 +508,28 @@ extern "C" int runet_wino4_output(const float* M, int n, int n_img, int h, int w
     RUNET_REQUIRE(M && y && dil_ok(h, w, dil) && runet_wino4_supported(h / dil, w / dil, 16, 4) && n > 0 && n % 2 == 0 && ldy >= n && ldy % 2 == 0, "bad arguments");
     RUNET_REQUIRE(((uintptr_t)M % 8) == 0 && ((uintptr_t)y % 8) == 0 && (!bias || ((uintptr_t)bias % 8) == 0), "alignment");
     const W4Geom g = geom(n_img, h, w, dil);
-    hipLaunchKernelGGL(wino4_output_kernel, dim3(cdiv(g.T * (n / 2), 256)), dim3(256), 0, (hipStream_t)stream, M, n, g, bias, y, ldy, accumulate);
+    hipLaunchKernelGGL(wino4_output_kernel<false>, dim3(cdiv(g.T * (n / 2), 256)), dim3(256), 0, (hipStream_t)stream, M, n, g, bias, y, ldy, accumulate, (float*)nullptr);
+    RUNET_CHECK_LAUNCH();
+}
+
+// Rows of the statistics partials runet_wino4_output_stats writes for n output channels, or 0 when it cannot take them (n / 2 must be a power of
+// two: the channel pairs of a block then repeat with period n / 2; dilated sub-image launches are not supported)
+extern "C" int runet_wino4_output_stats_parts(int n_img, int h, int w, int n, int dil) {
+    const int n2 = n / 2;
+    if (dil != 1 || n <= 0 || n % 2 || (n2 & (n2 - 1)) || !runet_wino4_supported(h, w, 16, 4)) return 0;
+    const long T = (long)n_img * (h / 4) * (w / 4);
+    const long parts = n2 >= 256 ? T : cdiv(T * n2, 256);
+    return parts > (1L << 30) ? 0 : (int)parts;
+}
+
+// runet_wino4_output that also leaves the BatchNorm statistics partials of y behind: stats [runet_wino4_output_stats_parts][n][3] = (count, mean, M2)
+// for runet_bn_stats_finalize (no pass of runet_bn_stats over y)
+extern "C" int runet_wino4_output_stats(const float* M, int n, int n_img, int h, int w, const float* bias, float* y, int ldy, int accumulate, float* stats,
+                                        void* stream) {
+    RUNET_REQUIRE(M && y && stats && runet_wino4_output_stats_parts(n_img, h, w, n, 1) > 0 && ldy >= n && ldy % 2 == 0, "bad arguments (n / 2 a power of two)");
+    RUNET_REQUIRE(((uintptr_t)M % 8) == 0 && ((uintptr_t)y % 8) == 0 && (!bias || ((uintptr_t)bias % 8) == 0), "alignment");
+    const W4Geom g = geom(n_img, h, w, 1);
+    hipLaunchKernelGGL(wino4_output_kernel<true>, dim3(cdiv(g.T * (n / 2), 256)), dim3(256), 0, (hipStream_t)stream, M, n, g, bias, y, ldy, accumulate, stats);
     RUNET_CHECK_LAUNCH();
 }
 
@@ -498,7 +569,7 @@ extern "C" int runet_wino4_conv(const float* x, int ldx, const float* U, const f
     hipLaunchKernelGGL(wino4_input_kernel<0>, dim3(cdiv(g.T * (k / 2), 256)), dim3(256), 0, st, x, ldx, k, g, V, W4Pre{});
     const int rc = runet_gemm_batched(V, k, g.T * k, U, (long)k * n, M, n, g.T * n, 36, (int)g.T, k, n, stream);
     if (rc) return rc;
-    hipLaunchKernelGGL(wino4_output_kernel, dim3(cdiv(g.T * (n / 2), 256)), dim3(256), 0, st, M, n, g, bias, y, ldy, accumulate);
+    hipLaunchKernelGGL(wino4_output_kernel<false>, dim3(cdiv(g.T * (n / 2), 256)), dim3(256), 0, st, M, n, g, bias, y, ldy, accumulate, (float*)nullptr);
     RUNET_CHECK_LAUNCH();
 }
 
@@ -520,7 +591,7 @@ extern "C" int runet_wino4_conv_x3(const float* x, int ldx, const void* Upacked,
     hipLaunchKernelGGL(wino4_input_kernel<0>, dim3(cdiv(g.T * (k / 2), 256)), dim3(256), 0, st, x, ldx, k, g, V, W4Pre{});
     const int rc = runet_gemm_x3_batched(V, k, g.T * k, Upacked, M, n, g.T * n, 36, (int)g.T, k, n, stream);
     if (rc) return rc;
-    hipLaunchKernelGGL(wino4_output_kernel, dim3(cdiv(g.T * (n / 2), 256)), dim3(256), 0, st, M, n, g, bias, y, ldy, accumulate);
+    hipLaunchKernelGGL(wino4_output_kernel<false>, dim3(cdiv(g.T * (n / 2), 256)), dim3(256), 0, st, M, n, g, bias, y, ldy, accumulate, (float*)nullptr);
     RUNET_CHECK_LAUNCH();
 }
 

@@ -482,13 +482,13 @@ def conv_fwd(x, w_hwio, bias=None, out=None, dil=1, accumulate=False, keep_v=Non
     kh, kw, cin_w, cout = w_hwio.shape
     if pre is not None:
         assert fuses_act_input(x, w_hwio) and dil == 1
-        return wino4_conv(x, wino4_weights(w_hwio), bias, out=out, accumulate=accumulate, keep_v=keep_v, dil=dil, pre=pre)
+        return wino4_conv(x, wino4_weights(w_hwio), bias, out=out, accumulate=accumulate, keep_v=keep_v, dil=dil, pre=pre, stats=stats)
     if _bf16_case(cin, cin_w):
         if out is None:
             out = empty_nhwc(n, h, w, cout, x)
         return _igemm_bf16(CONV_FWD, x, w_hwio, bias, out, n, h, w, cin, cout, kh, kw, dil, accumulate, False)
     if _wino4_case(h, w, kh, dil, cin, cout, cin_w):
-        return wino4_conv(x, wino4_weights(w_hwio), bias, out=out, accumulate=accumulate, keep_v=keep_v, dil=dil)
+        return wino4_conv(x, wino4_weights(w_hwio), bias, out=out, accumulate=accumulate, keep_v=keep_v, dil=dil, stats=stats)
     if _wino_case(h, w, kh, dil, cin, cout, cin_w, n, ld(x), ld(out) if out is not None else cout):
         return wino_conv(x, wino_weights(w_hwio), bias, out=out, accumulate=accumulate, stats=stats)
     if out is None:
@@ -1067,9 +1067,9 @@ def wino4_weights(w_hwio, dgrad=False, adjoint=False):
     return _cached(w_hwio, "wino4d" if dgrad else "wino4", make)
 
 
-def wino4_conv(x, U, bias=None, out=None, accumulate=False, keep_v=None, dil=1, pre=None):
+def wino4_conv(x, U, bias=None, out=None, accumulate=False, keep_v=None, dil=1, pre=None, stats=None):
     """keep_v: dict that receives {"V": transformed input [36*T*K]} - the weight gradient of the same convolution reuses it
-    (conv_wgrad(..., v=...)) instead of transforming x again.  pre: see conv_fwd."""
+    (conv_wgrad(..., v=...)) instead of transforming x again.  pre, stats: see conv_fwd."""
     n, h, w, k = x.shape
     x3 = U.dtype == torch.bfloat16                      # split-plane packing (wino4_weights under USE_X3)
     nn_ = U.kn[1] if x3 else U.shape[2]
@@ -1077,7 +1077,8 @@ def wino4_conv(x, U, bias=None, out=None, accumulate=False, keep_v=None, dil=1, 
         out = empty_nhwc(n, h, w, nn_, x)
     bp = bias.data_ptr() if bias is not None else None
     t = n * (h // 4) * (w // 4)
-    if _PROFILE is None and keep_v is None and pre is None:
+    sparts = lib.runet_wino4_output_stats_parts(n, h, w, nn_, dil) if (stats is not None and EPILOGUE_STATS) else 0
+    if _PROFILE is None and keep_v is None and pre is None and sparts == 0:
         ws = _workspace4(lib.runet_wino4_workspace_floats(n, h, w, k, nn_), x.device)
         fn = lib.runet_wino4_conv_x3 if x3 else lib.runet_wino4_conv
         check(fn(x.data_ptr(), ld(x), U.data_ptr(), bp, out.data_ptr(), ld(out), n, h, w, k, nn_, dil, int(accumulate), ws.data_ptr(),
@@ -1109,7 +1110,11 @@ def wino4_conv(x, U, bias=None, out=None, accumulate=False, keep_v=None, dil=1, 
         fl = 2.0 * 36 * t * k * nn_          # the position-GEMMs' own FLOPs; the convolution they implement is 4x that in direct-conv FLOPs
         kname = lib.runet_gemm_x3_kernel_name(36, t, k, nn_) if x3 else lib.runet_gemm_batched_kernel_name(36, t, k, nn_)
         _PROFILE.append((kname.decode(), 4.0 * fl, fl, e0, e1))
-    check(lib.runet_wino4_output(M, nn_, n, h, w, dil, bp, out.data_ptr(), ld(out), int(accumulate), stream()))
+    if sparts > 0:
+        sp = _stats_buf(stats, sparts, nn_, x.device)
+        check(lib.runet_wino4_output_stats(M, nn_, n, h, w, bp, out.data_ptr(), ld(out), int(accumulate), sp, stream()))
+    else:
+        check(lib.runet_wino4_output(M, nn_, n, h, w, dil, bp, out.data_ptr(), ld(out), int(accumulate), stream()))
     return out
 
 

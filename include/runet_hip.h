@@ -325,6 +325,10 @@ int runet_wino4_input_bn_bwd(const float* dy, int lddy, const float* x, int ldx,
                              const float* invstd, const float* scale, const float* shift, const float* sums, const float* factor_nc,
                              long m_total, float* Z, void* stream);
 int runet_wino4_output(const float* M, int n, int n_img, int h, int w, int dil, const float* bias, float* y, int ldy, int accumulate, void* stream);
+/* runet_wino4_output (dil = 1) that also leaves the BatchNorm statistics partials of y behind for runet_bn_stats_finalize: stats
+ * [runet_wino4_output_stats_parts(...)][n][3] = (count, mean, M2); _parts returns 0 where the kernel cannot take them (n / 2 not a power of two, dil != 1). */
+int runet_wino4_output_stats_parts(int n_img, int h, int w, int n, int dil);
+int runet_wino4_output_stats(const float* M, int n, int n_img, int h, int w, const float* bias, float* y, int ldy, int accumulate, float* stats, void* stream);
 /* The data gradient as the ADJOINT of the forward algorithm: Z = A dy A^T (runet_wino4_input mode 1 - the weight gradient's transform, shared),
  * M' = Z . U^T by the position GEMMs (runet_wino4_weights_x3 with dgrad = 2: the forward's U transposed, not rotated), and this gather-form
  * output transform dx = overlap-add of B M' B^T: one pass over dy and one filter transform less than the convolution form per layer. */

@@ -371,10 +371,11 @@ def test_conv_x3_matches_torch(n, h, w, ci, co, monkeypatch):
 
 
 @pytest.mark.parametrize("n,h,w,ci,co,k", [(2, 16, 16, 128, 128, 1), (3, 10, 12, 256, 64, 1), (1, 6, 10, 128, 384, 1), (2, 32, 32, 64, 64, 3),
-                                           (2, 20, 28, 32, 96, 3), (1, 8, 16, 16, 64, 3), (16, 64, 64, 128, 64, 3)])
+                                           (2, 20, 28, 32, 96, 3), (1, 8, 16, 16, 64, 3), (16, 64, 64, 128, 64, 3),
+                                           (2, 16, 16, 128, 128, 3), (1, 8, 12, 128, 512, 3), (3, 12, 20, 256, 128, 3)])      # the last three: F(4x4) output transform
 def test_epilogue_statistics_equal_the_separate_pass(n, h, w, ci, co, k, monkeypatch):
-    """BatchNorm statistics taken in the producing convolution's epilogue (runet_conv_x3_stats, runet_wino_conv_x3_stats +
-    runet_bn_stats_finalize) against the separate pass over the stored tensor (runet_bn_stats): scale / shift / saved mean / inverse
+    """BatchNorm statistics taken in the producing convolution's epilogue (runet_conv_x3_stats, runet_wino_conv_x3_stats,
+    runet_wino4_output_stats + runet_bn_stats_finalize) against the separate pass over the stored tensor (runet_bn_stats): scale / shift / saved mean / inverse
     standard deviation and the running statistics agree to 2e-6 relative (both are Chan combinations of exact per-block moments; the
     partition of the pixels differs), also with ragged row / tile counts and a bias."""
     ops = _ops()

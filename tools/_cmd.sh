@@ -1,5 +1,6 @@
 mkdir -p gpurun_out/r3
-export MASTER_ADDR=127.0.0.1 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 HSA_ENABLE_IPC_MODE_LEGACY=0 GPU_MAX_HW_QUEUES=8
-for i in 1 2 3 4 5 6 7 8 9 10; do
-MASTER_PORT=$((29500+i)) timeout -k 10 120 python tests/graph_ddp_child.py > gpurun_out/r3/child_$i.out 2> gpurun_out/r3/child_$i.err; echo "run $i rc=$? $(grep -c 'step' gpurun_out/r3/child_$i.err) $(tail -1 gpurun_out/r3/child_$i.out | cut -c1-60)"
+timeout -k 10 900 python -m pytest tests/test_gpu_conv.py tests/test_gpu_blocks.py tests/test_gpu_model.py -x -q > gpurun_out/r3/t.log 2>&1; tail -3 gpurun_out/r3/t.log
+for i in 1 2 3; do
+RUNET_NO_EPILOGUE_STATS=1 python bench.py --steps 30 --warmup 8 --no-cpu-baseline --no-roofline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('no epilogue stats', d['value'], d['ms_per_step'])"
+python bench.py --steps 30 --warmup 8 --no-cpu-baseline --no-roofline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('all              ', d['value'], d['ms_per_step'])"
 done
