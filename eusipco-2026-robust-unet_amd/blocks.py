@@ -269,12 +269,13 @@ def rb_forward(x, p: RBParams, training, mask=None, save=True, stats_hook=None):
     st = ops.stream()
     sm = Small(x.device)
     kv1, kv2 = ({}, {}) if save else (None, None)      # F(4x4) layers: the transformed inputs are kept for the weight gradients
-    t1, br = None, None
+    t1, br, fstem = None, None, (None, None)
     if p.ws is not None:
         if ops._stem_case(x.shape[3], p.cin_w, c, 3) and p.ws.shape[2] == p.cin_w:
-            t1, r = ops.stem_conv(x, p.w1, p.ws)       # RGB stem: conv1 and the shortcut convolution in one launch
+            fstem = ({}, {}) if (training and stats_hook is None) else (None, None)
+            t1, r = ops.stem_conv(x, p.w1, p.ws, stats3=fstem[0], stats1=fstem[1])       # RGB stem: conv1 and the shortcut convolution in one launch
             if stats_hook is None:
-                ss, hs, mean_s, invstd_s, _ = bn_coeff(r, p.bns, training, sm)
+                ss, hs, mean_s, invstd_s, _ = bn_coeff(r, p.bns, training, sm, fused=fstem[1])
         elif stats_hook is not None:
             r = ops.conv_fwd(x, p.ws)                  # SyncBN: no branch; the shortcut's statistics share bn1's message below
         else:
@@ -290,6 +291,8 @@ def rb_forward(x, p: RBParams, training, mask=None, save=True, stats_hook=None):
     f1 = {} if (training and stats_hook is None) else None
     if t1 is None:
         t1 = ops.conv_fwd(x, p.w1, keep_v=kv1, stats=f1)
+    elif fstem[0]:
+        f1 = fstem[0]                              # the stem kernel took bn1's statistics in its epilogue
     if p.ws is not None and stats_hook is not None:
         (ss, hs, mean_s, invstd_s), (s1, h1, mean1, invstd1) = bn_coeff_pair(r, p.bns, t1, p.bn1, training, sm, stats_hook)
     else:

@@ -28,6 +28,7 @@ struct StemFwd {
     const float* w3; const float* w1;                // [3][3][cin_w][cout], [cin_w][cout] or null
     float* y3; int ldy3; float* y1; int ldy1;
     int H, W, cin_w, cout;
+    float* stats3; float* stats1;                    // nullptr, or [blocks][cout][3] (count, mean, M2) partials of y3 / y1 (BatchNorm statistics)
 };
 
 // x halo of tile (n, r0, c0) -> LDS [row][col][4] (zero outside the image); 256 threads
@@ -82,6 +83,10 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(StemFwd a) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) breg[s][t] = bmat[(2 * s + kk) * (NT * 32) + t * 32 + li];
     }
+    // running (count, mean, M2) of this lane's channel of every tile over the pixels it stores (a.stats3 != nullptr)
+    float scnt = 0.f, smean[NT], sm2[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { smean[t] = 0.f; sm2[t] = 0.f; }
 #pragma unroll 1
     for (int seg = 0; seg < 2; ++seg) {
         const int r = 2 * wid + seg;
@@ -110,6 +115,56 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(StemFwd a) {
                 const int m = (i & 3) + 8 * (i >> 2) + 4 * kk;
                 if (c0 + m < a.W) y[(rowpix + m) * ldy + ch] = acc[t][i];
             }
+        }
+        if (a.stats3) {
+            // the segment's up to 16 pixels of this lane: two-pass moments, Chan-combined into the running ones (segment 0 first)
+            float cnt = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) cnt += (c0 + (i & 3) + 8 * (i >> 2) + 4 * kk < a.W) ? 1.f : 0.f;
+            if (cnt > 0.f) {
+                const float nt = scnt + cnt, f = cnt / nt, wgt = scnt * f;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    float s1 = 0.f, q = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) s1 += (c0 + (i & 3) + 8 * (i >> 2) + 4 * kk < a.W) ? acc[t][i] : 0.f;
+                    const float mu = s1 / cnt;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const float d = acc[t][i] - mu;
+                        q += (c0 + (i & 3) + 8 * (i >> 2) + 4 * kk < a.W) ? d * d : 0.f;
+                    }
+                    const float dl = mu - smean[t];
+                    smean[t] += dl * f;
+                    sm2[t] += q + dl * dl * wgt;
+                }
+                scnt = nt;
+            }
+        }
+    }
+    if (a.stats3) {
+        // lane halves (pixels + 4), then the four waves in wave order through LDS (bmat's storage: it is dead once every wave holds its B registers)
+        float* xch = bmat;                           // [4 waves][NT * 32][3]
+        __syncthreads();                             // every wave has loaded its B registers from bmat
+        const float ocnt = __shfl_xor(scnt, 32, 64);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float omean = __shfl_xor(smean[t], 32, 64), om2 = __shfl_xor(sm2[t], 32, 64);
+            const float nt = scnt + ocnt;
+            float mu = smean[t], q = sm2[t];
+            if (ocnt > 0.f) { const float f = ocnt / nt, dl = omean - mu; mu += dl * f; q += om2 + dl * dl * (scnt * f); }
+            if (kk == 0) { float* o = xch + ((wid * NT + t) * 32 + li) * 3; o[0] = nt; o[1] = mu; o[2] = q; }
+        }
+        __syncthreads();
+        for (int col = tid; col < NT * 32; col += 256) {
+            float cnt = 0.f, mu = 0.f, q = 0.f;
+            for (int wv = 0; wv < 4; ++wv) {
+                const float* o = xch + (wv * NT * 32 + col) * 3;
+                if (o[0] > 0.f) { const float nt = cnt + o[0], f = o[0] / nt, dl = o[1] - mu; mu += dl * f; q += o[2] + dl * dl * (cnt * f); cnt = nt; }
+            }
+            const int t = col >> 5;
+            float* dst = (t < n3 ? a.stats3 : a.stats1) + (((long)blockIdx.y * gridDim.x + blockIdx.x) * a.cout + (t < n3 ? t : t - n3) * 32 + (col & 31)) * 3;
+            dst[0] = cnt; dst[1] = mu; dst[2] = q;
         }
     }
 }
@@ -211,13 +266,30 @@ int wgrad_blocks(int total_tiles) { return total_tiles < 1024 ? total_tiles : 10
 
 extern "C" int runet_stem_supported(int cin_w, int cout) { return (cin_w >= 1 && cin_w <= 3 && cout % 32 == 0 && cout >= 32 && cout <= 64) ? 1 : 0; }
 
+static int stem_conv_launch(const float* x, int ldx, const float* w3, const float* w1, float* y3, int ldy3, float* y1, int ldy1, int n_img, int h, int w,
+                            int cin_w, int cout, float* stats3, float* stats1, void* stream);
+
 extern "C" int runet_stem_conv(const float* x, int ldx, const float* w3, const float* w1, float* y3, int ldy3, float* y1, int ldy1, int n_img,
                                int h, int w, int cin_w, int cout, void* stream) {
+    return stem_conv_launch(x, ldx, w3, w1, y3, ldy3, y1, ldy1, n_img, h, w, cin_w, cout, nullptr, nullptr, stream);
+}
+
+extern "C" int runet_stem_conv_stats_parts(int n_img, int h, int w) { return n_img * cdiv(h, TR) * cdiv(w, TC); }
+
+// runet_stem_conv that also leaves the BatchNorm statistics partials of y3 (and y1) behind: stats3 / stats1 [runet_stem_conv_stats_parts][cout][3]
+extern "C" int runet_stem_conv_stats(const float* x, int ldx, const float* w3, const float* w1, float* y3, int ldy3, float* y1, int ldy1, int n_img,
+                                     int h, int w, int cin_w, int cout, float* stats3, float* stats1, void* stream) {
+    RUNET_REQUIRE(stats3 && (!w1 || stats1), "stats3 (and stats1 with a 1x1 filter) must not be NULL");
+    return stem_conv_launch(x, ldx, w3, w1, y3, ldy3, y1, ldy1, n_img, h, w, cin_w, cout, stats3, stats1, stream);
+}
+
+static int stem_conv_launch(const float* x, int ldx, const float* w3, const float* w1, float* y3, int ldy3, float* y1, int ldy1, int n_img, int h, int w,
+                            int cin_w, int cout, float* stats3, float* stats1, void* stream) {
     RUNET_REQUIRE(x && w3 && y3 && (!w1 || y1), "null pointer");
     RUNET_REQUIRE(runet_stem_supported(cin_w, cout), "stem kernel: 1..3 input channels, 32 or 64 output channels");
     RUNET_REQUIRE(ldx >= 4 && ldx % 4 == 0 && ((uintptr_t)x % 16) == 0, "x must be NHWC padded to (a multiple of) 4 channels, 16-byte aligned");
     RUNET_REQUIRE(n_img > 0 && h > 0 && w > 0 && ldy3 >= cout && (!w1 || ldy1 >= cout), "bad shape");
-    StemFwd a{x, ldx, w3, w1, y3, ldy3, y1, ldy1, h, w, cin_w, cout};
+    StemFwd a{x, ldx, w3, w1, y3, ldy3, y1, ldy1, h, w, cin_w, cout, stats3, stats1};
     const dim3 grid(cdiv(h, TR) * cdiv(w, TC), n_img);
     const int nt = (cout / 32) * (w1 ? 2 : 1);
     hipStream_t st = (hipStream_t)stream;

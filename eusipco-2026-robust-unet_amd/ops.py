@@ -396,14 +396,22 @@ def _stem_case(cin, cin_w, cout, kh, dil=1):
     return USE_STEM_KERNELS and cin == 4 and kh in (1, 3) and dil == 1 and bool(lib.runet_stem_supported(cin_w, cout))
 
 
-def stem_conv(x, w3, w1=None):
-    """x [N,H,W,4] (RGB + zero) -> (conv3x3(x, w3), conv1x1(x, w1) or None) in one launch; w3 [3,3,cin_w,C], w1 [1,1,cin_w,C]."""
+def stem_conv(x, w3, w1=None, stats3=None, stats1=None):
+    """x [N,H,W,4] (RGB + zero) -> (conv3x3(x, w3), conv1x1(x, w1) or None) in one launch; w3 [3,3,cin_w,C], w1 [1,1,cin_w,C].
+    stats3 / stats1: dicts that receive the BatchNorm statistics partials of the two outputs (see conv_fwd's `stats`)."""
     n, h, w, _ = x.shape
     _, _, cin_w, cout = w3.shape
     y3 = empty_nhwc(n, h, w, cout, x)
     y1 = empty_nhwc(n, h, w, cout, x) if w1 is not None else None
-    check(lib.runet_stem_conv(x.data_ptr(), ld(x), w3.data_ptr(), w1.data_ptr() if w1 is not None else None, y3.data_ptr(), ld(y3),
-                              y1.data_ptr() if y1 is not None else None, ld(y1) if y1 is not None else 0, n, h, w, cin_w, cout, stream()))
+    args = (x.data_ptr(), ld(x), w3.data_ptr(), w1.data_ptr() if w1 is not None else None, y3.data_ptr(), ld(y3),
+            y1.data_ptr() if y1 is not None else None, ld(y1) if y1 is not None else 0, n, h, w, cin_w, cout)
+    if EPILOGUE_STATS and stats3 is not None and (w1 is None or stats1 is not None):
+        parts = lib.runet_stem_conv_stats_parts(n, h, w)
+        s3 = _stats_buf(stats3, parts, cout, x.device)
+        s1 = _stats_buf(stats1, parts, cout, x.device) if w1 is not None else None
+        check(lib.runet_stem_conv_stats(*args, s3, s1, stream()))
+    else:
+        check(lib.runet_stem_conv(*args, stream()))
     return y3, y1
 
 

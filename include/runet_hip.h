@@ -347,6 +347,11 @@ int runet_wino4_wgrad(const float* x, int ldx, const float* dy, int ldy, float* 
 int runet_stem_supported(int cin_w, int cout);
 int runet_stem_conv(const float* x, int ldx, const float* w3, const float* w1, float* y3, int ldy3, float* y1, int ldy1, int n_img,
                     int h, int w, int cin_w, int cout, void* stream);
+/* runet_stem_conv that also leaves the BatchNorm statistics partials of y3 (and y1) behind for runet_bn_stats_finalize:
+ * stats3 / stats1 [runet_stem_conv_stats_parts(n_img, h, w)][cout][3] = (count, mean, M2) per 8 x 32 pixel tile */
+int runet_stem_conv_stats_parts(int n_img, int h, int w);
+int runet_stem_conv_stats(const float* x, int ldx, const float* w3, const float* w1, float* y3, int ldy3, float* y1, int ldy1, int n_img,
+                          int h, int w, int cin_w, int cout, float* stats3, float* stats1, void* stream);
 long runet_stem_wgrad_workspace_floats(int n_img, int h, int w, int cin_w, int cout, int ksize);
 int runet_stem_wgrad(const float* x, int ldx, const float* dy, int ldy, float* dw, float* workspace, long workspace_floats, int n_img,
                      int h, int w, int cin_w, int cout, int ksize, void* stream);

@@ -426,3 +426,35 @@ def test_transposed_conv_weight_gradient_on_the_split_operand_gemm(n, h, w, ci, 
     got = ops.convt_wgrad(xd, dcat[..., co:])
     err = float((got.double().cpu() - ref).abs().max() / ref.abs().max())
     assert err <= 2e-5, err
+
+
+@pytest.mark.parametrize("n,h,w,co", [(2, 24, 40, 64), (1, 20, 32, 64), (3, 8, 100, 32)])
+def test_stem_epilogue_statistics_equal_the_separate_pass(n, h, w, co):
+    """the RGB stem's two outputs (conv1 and the 1x1 shortcut of the first ResidualBlock, one launch): BatchNorm statistics from the kernel's
+    epilogue (runet_stem_conv_stats) against the pass over the stored tensors, ragged tile rows / columns included; outputs unchanged"""
+    ops = _ops()
+    blocks = importlib.import_module("eusipco-2026-robust-unet_amd.blocks")
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(n + h + w)
+    x = torch.zeros(n, h, w, 4)
+    x[..., :3] = torch.rand(n, h, w, 3, generator=g)
+    x = x.to(dev)
+    w3 = (torch.randn(3, 3, 3, co, generator=g) / 27 ** 0.5).to(dev)
+    w1 = (torch.randn(1, 1, 3, co, generator=g) / 3 ** 0.5).to(dev)
+
+    def bn_state():
+        return blocks.BNState(torch.full((co,), 1.5, device=dev), torch.full((co,), -0.25, device=dev), torch.zeros(co, device=dev),
+                              torch.ones(co, device=dev), torch.zeros((), device=dev, dtype=torch.int64))
+    s3, s1 = {}, {}
+    y3, y1 = ops.stem_conv(x, w3, w1, stats3=s3, stats1=s1)
+    z3, z1 = ops.stem_conv(x, w3, w1)
+    assert torch.equal(y3, z3) and torch.equal(y1, z1)
+    assert "part" in s3 and "part" in s1
+    for y, st in ((y3, s3), (y1, s1)):
+        bn_a, bn_b = bn_state(), bn_state()
+        got = blocks.bn_coeff(y, bn_a, True, blocks.Small(dev), fused=st)[:4]
+        ref = blocks.bn_coeff(y, bn_b, True, blocks.Small(dev))[:4]
+        for a, r, name in zip(got, ref, ("scale", "shift", "mean", "invstd")):
+            err = float((a - r).abs().max() / r.abs().max())
+            assert err <= 2e-6, (name, err)
+        assert float((bn_a.running_var - bn_b.running_var).abs().max() / bn_b.running_var.abs().max()) <= 2e-6
