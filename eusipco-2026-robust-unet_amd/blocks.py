@@ -281,10 +281,11 @@ def rb_forward(x, p: RBParams, training, mask=None, save=True, stats_hook=None):
         else:
             # the shortcut branch (1x1 convolution + its BatchNorm statistics) runs beside conv1 .. the attention maps, joins at rb_out
             sm.f(4)                                    # the arena's buffer is allocated on the main stream
+            r = ops.main_pool(ops.empty_nhwc(n, h, w, c, x))          # ... and so is the branch's result (side_branch.join)
             br = ops.side_branch(stats_hook is None)
             with br:
                 fs = {} if training else None
-                r = ops.conv_fwd(x, p.ws, stats=fs)
+                ops.conv_fwd(x, p.ws, out=r, stats=fs)
                 ss, hs, mean_s, invstd_s, _ = bn_coeff(r, p.bns, training, sm, fused=fs)
     else:
         r, ss, hs, mean_s, invstd_s = x, None, None, None, None
@@ -611,10 +612,12 @@ def gate_x_branch(skip, p: UpGateParams, training, sm, stats_hook=None):
     """W_x(skip) + its BatchNorm statistics on the side stream: independent of the gate signal, so upgate_forward starts it in front of
     the transposed convolution.  -> (branch handle, x1, (scale, shift, mean, invstd))"""
     sm.f(4)
+    n, h, w, _ = skip.shape
+    x1 = ops.main_pool(ops.empty_nhwc(n, h, w, p.wx.shape[3], skip))      # allocated on the main stream (side_branch.join)
     br = ops.side_branch(stats_hook is None)
     with br:
         fx = {} if (training and stats_hook is None) else None
-        x1 = ops.conv_fwd(skip, p.wx, p.bx, stats=fx)
+        ops.conv_fwd(skip, p.wx, p.bx, out=x1, stats=fx)
         # SyncBN: the statistics wait for gate_forward, where they share W_g's message
         cx = bn_coeff(x1, p.bnx, training, sm, fused=fx)[:4] if stats_hook is None else None
     return br, x1, cx

@@ -619,6 +619,7 @@ def conv_dgrad(dy, w_hwio, out=None, dil=1, accumulate=False, keep_z=None, bn=No
 # and they are matrix-core work while much of the chain (BatchNorm / attention backward, Winograd transforms) is HBM-bound.
 USE_WGRAD_STREAM = os.environ.get("RUNET_NO_WGRAD_STREAM", "0") != "1"
 GRAPH_SIDE = os.environ.get("RUNET_GRAPH_SIDE", "0") == "1"      # measurement knob: keep the fork / join inside a hipGraph capture
+SIDE_RECORD_STREAM = os.environ.get("RUNET_SIDE_RECORD_STREAM", "0") == "1"      # measurement knob: the round-2 lifetime rule (Tensor.record_stream)
 _side = {}
 
 
@@ -641,6 +642,13 @@ class wgrad_side_stream:
         s = _side.pop("active", None)
         if s is not None:
             torch.cuda.current_stream().wait_stream(s)
+        # Tensors the weight-gradient stream read or wrote were kept alive up to here (_on_side) instead of being handed to
+        # Tensor.record_stream: they are released in host order BEHIND the wait above, so the caching allocator (which reuses a block for the
+        # stream it was allocated on, i.e. the current one) can take them back at once and the same way every step.  With record_stream the
+        # reuse of a block depended on whether the GPU had already passed the recording event when the host - up to a step ahead - asked
+        # again: the pool never reached a steady state (tools/host_lead.py: ~2 hipMalloc per step, +0.6 GB reserved per step without end,
+        # host time per step 25 ms instead of 7).
+        _side.pop("keep", None)
         return False
 
 
@@ -690,14 +698,23 @@ class side_branch:
         return False
 
     def join(self, *tensors):
-        """The current stream waits for the branch; tensors the branch allocated are marked as used by the current stream."""
+        """The current stream waits for the branch.  `tensors`: results the branch wrote that the current stream goes on to use - allocate
+        them BEFORE entering the branch (from the current stream's pool, like everything else the pass keeps); a tensor that was allocated
+        inside the branch (the branch stream's pool) is marked with record_stream instead, which is correct but lets the allocator's reuse
+        depend on GPU progress (see wgrad_side_stream.__exit__)."""
         if self.s is not None:
             cur = torch.cuda.current_stream()
             cur.wait_stream(self.s)
             for t in tensors:
-                if t is not None:
+                if t is not None and (SIDE_RECORD_STREAM or getattr(t, "_runet_main_pool", False) is False):
                     t.record_stream(cur)
             self.s = None
+
+
+def main_pool(t):
+    """Mark a tensor allocated on the current stream that a forward branch will fill: side_branch.join() then needs no record_stream for it."""
+    t._runet_main_pool = True
+    return t
 
 
 def _on_side(fn, tensors):
@@ -720,9 +737,15 @@ def _on_side(fn, tensors):
             r = fn()
         finally:
             _tls.override = None
+    if SIDE_RECORD_STREAM:
+        for t in tensors:
+            if t is not None:
+                t.record_stream(s)
+        return r
+    keep = _side.setdefault("keep", [])
     for t in tensors:
         if t is not None:
-            t.record_stream(s)
+            keep.append(t)                       # released by wgrad_side_stream.__exit__, behind the join (no record_stream: see there)
     return r
 
 
