@@ -318,4 +318,6 @@ class _DeepLabFn(torch.autograd.Function):
             raise RuntimeError("DeepLabV3Plus backward called twice")
         G = dl_backward(ctx.net, ctx.C, dprob.contiguous())
         ctx.C = None
-        return (None, None, None) + tuple(G[k] for k in ctx.names)
+        # the parameter gradients go to buffers at fixed addresses and are assigned here (ops.deliver_grads), not returned to autograd
+        ops.deliver_grads(ctx.net, [p for _, p in ctx.net.named_parameters()], [G[k] for k in ctx.names])
+        return (None, None, None) + (None,) * len(ctx.names)

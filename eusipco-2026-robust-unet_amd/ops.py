@@ -1224,3 +1224,29 @@ def wino4_wgrad(x, dy, out=None, v=None, dil=1, z=None):
         _PROFILE.append(("gemm_tn_x3_kernel" if x3 else ("gemm_tn_kernel<true>" if t % 16 == 0 else "gemm_tn_kernel<false>"), 4.0 * fl, fl, e0, e1))
     check(lib.runet_wino4_wgrad_output(dU, -(-t // rps), cin, cout, out.data_ptr(), stream()))
     return out
+
+
+# ---- gradients at fixed addresses for the models without a flat arena (DeepLabV3+, plain U-Net).  Their backward passes produce fresh
+# tensors; handed to autograd these became new `p.grad` tensors every step, so FusedAdam's device pointer table was rebuilt and uploaded
+# (a blocking host-to-device copy) every step - the host could never run ahead of the GPU (tools/host_lead.py: host time == GPU time) - and a
+# captured step was impossible.  deliver_grads copies them (one multi-tensor launch) into per-parameter buffers that live as long as the model
+# and assigns those as p.grad itself.
+def deliver_grads(net, params, grads):
+    """params / grads: matching lists (grads in the parameters' logical shapes).  Sets p.grad (adds to an existing one) -> None"""
+    bufs = getattr(net, "_grad_bufs", None)
+    if bufs is None or len(bufs) != len(params) or any(b.shape != p.shape or b.device != p.device for b, p in zip(bufs, params)):
+        bufs = net._grad_bufs = [torch.empty_like(p, memory_format=torch.preserve_format) for p in params]
+    fresh = [p.grad is None for p in params]
+    if all(fresh):
+        torch._foreach_copy_(bufs, list(grads))
+        for p, b in zip(params, bufs):
+            if p.requires_grad:
+                p.grad = b
+        return
+    for p, g, f in zip(params, grads, fresh):      # gradient accumulation: the rare path
+        if not p.requires_grad:
+            continue
+        if f:
+            p.grad = g.clone()
+        else:
+            p.grad.add_(g)

@@ -59,7 +59,9 @@ class TrainStep:
         self.graph_mode = bool(graph)
         if self.graph_mode:
             self.optimizer.capturable = True
-            model.grad_arena()            # gradients live at fixed addresses (views of one arena): the Adam pointer table stays valid
+            if hasattr(model, "grad_arena"):
+                model.grad_arena()        # gradients live at fixed addresses (views of one arena): the Adam pointer table stays valid
+            # (DeepLabV3+ / the plain U-Net: ops.deliver_grads keeps per-parameter gradient buffers for the life of the model)
         self._eager_left = int(graph_warmup)
         self._graph = None
         self._static = None
