@@ -162,3 +162,30 @@ def test_split_operand_dispatch_policy():
     with ops.precision("bf16"):
         assert not case(512, 256)                                        # reduced-precision modes have their own kernels
     assert case(512, 256)
+
+
+def test_deliver_grads_keeps_addresses_and_accumulates():
+    """ops.deliver_grads (DeepLabV3+ / plain U-Net): gradients land in per-parameter buffers with the parameters' own strides and keep their
+    address from step to step (the fused optimizer's pointer table stays valid); a second backward without zero_grad accumulates."""
+    ops = importlib.import_module("eusipco-2026-robust-unet_amd.ops")
+
+    class Net:
+        pass
+    net = Net()
+    w = torch.nn.Parameter(torch.randn(3, 3, 4, 8).permute(3, 2, 0, 1))          # logical OIHW over HWIO storage, like the models' weights
+    b = torch.nn.Parameter(torch.randn(8))
+    frozen = torch.nn.Parameter(torch.randn(2), requires_grad=False)
+    params = [w, b, frozen]
+    g1 = [torch.randn(8, 4, 3, 3), torch.randn(8), torch.zeros(2)]
+    ops.deliver_grads(net, params, g1)
+    assert torch.equal(w.grad, g1[0]) and torch.equal(b.grad, g1[1]) and frozen.grad is None
+    assert w.grad.stride() == w.stride(), "the gradient must be dense like the parameter (FusedAdam walks raw storage)"
+    ptrs = [w.grad.data_ptr(), b.grad.data_ptr()]
+    w.grad = None
+    b.grad = None
+    g2 = [torch.randn(8, 4, 3, 3), torch.randn(8), torch.zeros(2)]
+    ops.deliver_grads(net, params, g2)
+    assert [w.grad.data_ptr(), b.grad.data_ptr()] == ptrs
+    assert torch.equal(w.grad, g2[0])
+    ops.deliver_grads(net, params, g1)                                             # no zero_grad in between: accumulate
+    assert torch.allclose(w.grad, g1[0] + g2[0]) and torch.allclose(b.grad, g1[1] + g2[1])
