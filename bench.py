@@ -271,9 +271,15 @@ def run_rank(args):
         prof = ops.start_conv_profile() if profile else None
         barrier()
         t0 = time.perf_counter()
+        per_step, ts = [], t0
         for _ in range(steps):
             loss = step(x, y)
-        host_ms[0] = 1e3 * (time.perf_counter() - t0) / steps      # time the host needed to ENQUEUE a step (diagnostic: host- vs GPU-bound)
+            te = time.perf_counter()
+            per_step.append(te - ts)
+            ts = te
+        # time the host needs to ENQUEUE a step (diagnostic: host- vs GPU-bound): the lower quartile of the per-step host times - once the
+        # host is a queue's depth ahead of the GPU it blocks inside launches, so the mean would just repeat the GPU's step time
+        host_ms[0] = 1e3 * sorted(per_step)[len(per_step) // 4]
         barrier()
         dt = time.perf_counter() - t0
         roof = ops.stop_conv_profile(prof) if prof is not None else None
