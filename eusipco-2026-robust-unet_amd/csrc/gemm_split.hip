@@ -426,10 +426,16 @@ static bool nn_x3_narrow(int batch, int rows, int n) {
     if (force == 64) return true;
     if (force == 128) return false;
     if (n <= 64) return true;
+    // narrower tiles only where 128 x 128 tiles cannot fill the chip once (512 resident blocks): small-batch shards.  The earlier rule also chose
+    // them for unevenly filled last waves (balance < 0.8); with the loop's prefetch fixed the two rules measure the same at 16 x 256^2 (586.3 vs 586.4
+    // img/s) and the simpler one is 0.3 % ahead on the 2-image shard
+    static const int mode = getenv("RUNET_GEMM_X3_BALANCE") ? atoi(getenv("RUNET_GEMM_X3_BALANCE")) : 0;      // measurement knob: 1 = the earlier rule
     const long b128 = (long)cdiv(rows, 128) * cdiv(n, 128) * batch;
-    const double rounds = b128 / 512.0;
-    const double bal = rounds / (double)((b128 + 511) / 512);
-    return bal < 0.8;
+    if (mode == 1) {
+        const double rounds = b128 / 512.0;
+        return rounds / (double)((b128 + 511) / 512) < 0.8;
+    }
+    return b128 < 512;
 }
 
 extern "C" const char* runet_gemm_x3_kernel_name(int batch, int rows, int k, int n) {
