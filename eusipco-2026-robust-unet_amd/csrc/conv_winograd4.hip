@@ -16,6 +16,7 @@
 #include "runet_common.h"
 #include "../../include/runet_hip.h"
 #include "derive_weights.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -428,8 +429,9 @@ bool dil_ok(int h, int w, int dil) { return dil >= 1 && dil <= 8 && h % dil == 0
 
 // rows (tiles) per split of the weight-gradient GEMMs: enough splits for ~512 blocks, at least 64 tiles each, 16-aligned
 int wgrad_rows_per_split(long T, int cin, int cout) {
+    static const int target = getenv("RUNET_W4_WGRAD_BLOCKS") ? atoi(getenv("RUNET_W4_WGRAD_BLOCKS")) : 512;      // measurement knob (256: 582.1, 512: 580.9, 1024: 576.1, 2048: 572.1 img/s)
     const long blocks = (long)cdiv(cin, 128) * cdiv(cout, 128) * 36;
-    long s = cdiv(512, blocks);
+    long s = cdiv(target, blocks);
     const long maxs = T / 64 > 0 ? T / 64 : 1;
     if (s > maxs) s = maxs;
     if (s < 1) s = 1;
