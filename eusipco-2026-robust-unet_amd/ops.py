@@ -426,6 +426,9 @@ def stem_conv(x, w3, w1=None, stats3=None, stats1=None):
 USE_CONV_X3 = os.environ.get("RUNET_NO_CONV_X3", "0") != "1"
 CONV_X3_MIN_K = int(os.environ.get("RUNET_CONV_X3_MIN_K", "128"))        # smallest contraction (taps x channels); from 2x this on: any width
 CONV_X3_WIDE_N = int(os.environ.get("RUNET_CONV_X3_WIDE_N", "128"))      # output channels needed while the contraction is below 2x MIN_K
+# The transposed forward with a 128-deep contraction takes the split-operand kernel also with fewer than CONV_X3_WIDE_N output channels (up1:
+# 128 -> 64 @ 128^2: its four taps make it matrix-bound on the f32 implicit GEMM, 267 us at 1.5 TB/s; 204 us here).  RUNET_NO_CONVT_X3_NARROW=1: off.
+CONVT_X3_NARROW = os.environ.get("RUNET_NO_CONVT_X3_NARROW", "0") != "1"
 _X3_KIND = {CONV_FWD: "cx3f", CONV_DGRAD: "cx3d", CONVT_FWD: "cx3uf", CONVT_DGRAD: "cx3ud"}      # "...d": refilled with the backward kinds
 
 
@@ -818,7 +821,7 @@ def convt_fwd(x, w_hwio, bias=None, out=None):
         out = empty_nhwc(n, 2 * h, 2 * w, cout, x)
     if _bf16_case(cin, cin_w):
         return _igemm_bf16(CONVT_FWD, x, w_hwio, bias, out, n, h, w, cin, cout, 2, 2, 1, False, False)
-    if _conv_x3_case(x, cin, cin_w, cout):
+    if _conv_x3_case(x, cin, cin_w, cout) or (CONVT_X3_NARROW and cout >= 32 and _conv_x3_case(x, cin, cin_w, max(cout, CONV_X3_WIDE_N))):
         return _conv_x3(CONVT_FWD, x, w_hwio, bias, out, n, h, w, cin, cout, False)
     _igemm(CONVT_FWD, x.data_ptr(), ld(x), w_hwio.data_ptr(), bias.data_ptr() if bias is not None else None,
            out.data_ptr(), ld(out), n, h, w, cin, cin_w, cout, 2, 2, 1, 0)
