@@ -126,7 +126,7 @@ _derive_tables = {}
 def _derive_multi(entries):
     """One launch on ops.stream() refilling, in place, every cache entry of `entries` (all with a descriptor).  The device table depends on
     addresses only, so it is built and uploaded the first time a set of entries is seen - never during a stream capture (-> False then)."""
-    key = tuple((ent[6], ent[1].data_ptr()) for ent in entries)
+    key = (entries[0][1].device.index,) + tuple((ent[6], ent[1].data_ptr()) for ent in entries)      # addresses repeat across devices
     tab = _derive_tables.get(key)
     if tab is None:
         if torch.cuda.is_current_stream_capturing():
